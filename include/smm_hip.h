@@ -1,0 +1,185 @@
+/*
+ * smm_hip.h -- C ABI of libsmm_hip.so, the MI355X (gfx950) engine behind
+ * sparse_matrix_multiply().  Plain C: pointers and sizes only, no C++/torch types.
+ *
+ * Two layers are exported by the same library:
+ *
+ *  (1) The LEGACY entry points the reference's Python wrapper binds by name
+ *      (reference sparse_matrix_mult/matrix_ops.py:147-171, call sites :195,333,346,348,
+ *      360,362,336,351,365; declarations include/functions.h:43-84).  Struct layout is the
+ *      one that wrapper declares -- `int` dims (matrix_ops.py:26-33: 40-byte sparsemat,
+ *      :44-48: 16-byte darray) -- NOT the size_t layout of include/matrix_def.h at HEAD
+ *      (SURVEY F1).  Host arrays in, libc-malloc'd host arrays out, freed by destroy_*.
+ *
+ *  (2) The v2 API our own matrix_ops.py, bench.py and the multi-GPU driver call: operands
+ *      live in HBM behind opaque handles, results are written into caller-owned DEVICE (or
+ *      host) buffers, row pointers / nnz are int64 (nnz(C) of the 50k x 50k d=0.01 config
+ *      is 2.48e9 > INT32_MAX), every call returns 0 or a negative smm_status and
+ *      smm_last_error() gives the message.  Nothing here falls back to a CPU path: with no
+ *      usable GPU every compute entry point fails with SMM_ERR_NO_DEVICE.
+ */
+#ifndef SMM_HIP_H
+#define SMM_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status / flags */
+enum smm_status {
+    SMM_OK = 0,
+    SMM_ERR_NO_DEVICE = -1,   /* no gfx950 device visible / HIP init failed            */
+    SMM_ERR_INVALID   = -2,   /* bad argument, shape mismatch, malformed CSR            */
+    SMM_ERR_ALLOC     = -3,   /* hipMalloc / malloc failed                              */
+    SMM_ERR_HIP       = -4,   /* a HIP runtime call or kernel launch failed             */
+    SMM_ERR_OVERFLOW  = -5    /* result does not fit the legacy int32 ABI               */
+};
+
+enum smm_flags {
+    SMM_SYMMETRIC   = 1,  /* keep only i <= col   (sparsework.cpp:217, sparse_sparse_dense.cpp:59) */
+    SMM_FULL_MATRIX = 2,  /* triple_product compute_full_matrix=1 (sparse_sparse_dense.cpp:201,213) */
+    SMM_UNORDERED   = 4   /* numeric phase may add products in any order (LDS atomics across
+                             waves): values then agree with the reference to rounding
+                             (<= 1e-10 relative) instead of bit for bit.  indptr / indices
+                             are unaffected.                                             */
+};
+
+typedef struct smm_ctx  smm_ctx;   /* one device + one stream + a workspace arena        */
+typedef struct smm_csr  smm_csr;   /* a CSR operand resident in HBM (+ cached tile index) */
+typedef struct smm_plan smm_plan;  /* result of the symbolic phase of one product         */
+
+/* ------------------------------------------------------------------ context */
+int         smm_device_count(void);              /* number of usable devices, 0 if none  */
+const char *smm_last_error(void);                /* thread-local message of the last failure */
+/* hip_stream: a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream),
+ * or NULL for a stream the context creates and owns. */
+int  smm_ctx_create(int device, void *hip_stream, smm_ctx **out);
+void smm_ctx_destroy(smm_ctx *ctx);
+int  smm_ctx_synchronize(smm_ctx *ctx);
+/* Per-kernel timing with HIP events on the context's stream (bench.py's roofline leg).
+ * enable=1 starts recording; smm_ctx_kernel_time returns the accumulated milliseconds and
+ * launch count of the named kernel since the last reset (name as printed by rocprofv3,
+ * without template arguments: "smm_numeric", "smm_symbolic", ...). */
+int  smm_ctx_timing(smm_ctx *ctx, int enable);
+int  smm_ctx_timing_reset(smm_ctx *ctx);
+int  smm_ctx_kernel_time(smm_ctx *ctx, const char *kernel, double *ms_total, int64_t *launches);
+/* Tuning knobs (0 keeps the default): LDS accumulator columns per workgroup and waves per
+ * workgroup of the numeric kernels. */
+int  smm_ctx_tune(smm_ctx *ctx, int lds_cols, int waves);
+
+/* ------------------------------------------------------------------ operands
+ * Replaces create_sparsemat + the three memmoves of csr_to_sparsemat
+ * (matrix_ops.py:187-202; src/memfunctions.cpp:117-131).  indptr/indices are int32 as in
+ * the reference (`int* rowPtr, colInd`, include/matrix_def.h:21-22); nnz < 2^31.
+ * The CSR is validated on the device (monotone indptr, indices in range); a malformed
+ * operand is rejected with SMM_ERR_INVALID instead of faulting a kernel. */
+int  smm_csr_from_host(smm_ctx *ctx, int64_t rows, int64_t cols, int64_t nnz,
+                       const int32_t *indptr, const int32_t *indices, const double *data,
+                       smm_csr **out);
+/* Borrow arrays already in HBM (no copy; they must outlive the handle). */
+int  smm_csr_from_device(smm_ctx *ctx, int64_t rows, int64_t cols, int64_t nnz,
+                         const int32_t *d_indptr, const int32_t *d_indices, const double *d_data,
+                         smm_csr **out);
+void smm_csr_destroy(smm_csr *m);
+int64_t smm_csr_rows(const smm_csr *m);
+int64_t smm_csr_cols(const smm_csr *m);
+int64_t smm_csr_nnz(const smm_csr *m);
+/* 1 when every row has strictly increasing column indices (scipy "canonical" CSR). */
+int  smm_csr_is_canonical(smm_ctx *ctx, smm_csr *m);
+/* products[i] = sum over nonzeros (i,r) of A of nnz(B[r,:]) -- the work measure used to
+ * balance contiguous row shards across GPUs (replaces limits(), src/workdivision.cpp:16-89,
+ * which balances row counts).  Host output, a.rows entries. */
+int  smm_row_products(smm_ctx *ctx, const smm_csr *a, const smm_csr *b, int64_t *products_host);
+
+/* ------------------------------------------------------------------ CSR x CSR -> CSR
+ * Replaces sparse_nosym / sparse_sym (src/sparse_sparse_sparse.cpp:172-299 / :41-155) and
+ * the row kernels sparsework_nosym / sparsework_sym (src/sparsework.cpp:12-149 / :156-300).
+ * Two phases, as the reference's count-then-stitch driver: symbolic produces per-row counts
+ * and the first-touch-ordered column lists and returns nnz(C); the caller allocates
+ * c_indices / c_data (device) of that size; numeric fills indptr (int64, a.rows+1),
+ * indices (int32, reference order) and data.
+ * a_row_offset: global index of A's row 0 when A is one contiguous row shard of a larger
+ * matrix (only the SMM_SYMMETRIC filter i <= col looks at it). */
+int  smm_spgemm_symbolic(smm_ctx *ctx, smm_csr *a, smm_csr *b, int flags, int64_t a_row_offset,
+                         smm_plan **plan, int64_t *nnz_out);
+int  smm_spgemm_numeric(smm_ctx *ctx, smm_plan *plan,
+                        int64_t *d_c_indptr, int32_t *d_c_indices, double *d_c_data);
+/* Same, results copied into host buffers (numpy arrays owned by the caller). */
+int  smm_spgemm_numeric_host(smm_ctx *ctx, smm_plan *plan,
+                             int64_t *c_indptr, int32_t *c_indices, double *c_data);
+/* Only the int64 row pointer of the planned product (device->host, a.rows+1 entries). */
+int  smm_plan_indptr_host(smm_ctx *ctx, smm_plan *plan, int64_t *c_indptr);
+int64_t smm_plan_nnz(const smm_plan *plan);
+void smm_plan_destroy(smm_plan *plan);
+
+/* ------------------------------------------------------------------ CSR x CSR -> dense
+ * Replaces dense_nosym / dense_sym (src/sparse_sparse_dense.cpp:79-131 / :13-74).
+ * d_c: a.rows x b.cols row-major float64 in HBM; every element is written (cells the
+ * reference leaves at calloc's 0.0 are written as 0.0). */
+int  smm_spgemm_dense(smm_ctx *ctx, smm_csr *a, smm_csr *b, int flags, int64_t a_row_offset,
+                      double *d_c);
+int  smm_spgemm_dense_host(smm_ctx *ctx, smm_csr *a, smm_csr *b, int flags, int64_t a_row_offset,
+                           double *c);
+
+/* ------------------------------------------------------------------ H * Q * H^T
+ * Replaces triple_product (src/sparse_sparse_dense.cpp:141-249).  Rows
+ * [row_begin,row_end) of the n x n result are computed; d_c points at row row_begin of a
+ * row-major buffer with leading dimension n.  Without SMM_FULL_MATRIX only k >= i is
+ * computed and the rest of each row is written as 0.0.  With SMM_FULL_MATRIX the whole
+ * range must be [0,n) and the reference's behaviour is reproduced exactly: every
+ * off-diagonal cell holds S[i,k] + S[k,i]. */
+int  smm_triple_product(smm_ctx *ctx, smm_csr *h, smm_csr *q, int flags,
+                        int64_t row_begin, int64_t row_end, double *d_c);
+int  smm_triple_product_host(smm_ctx *ctx, smm_csr *h, smm_csr *q, int flags,
+                             int64_t row_begin, int64_t row_end, double *c);
+
+/* ------------------------------------------------------------------ device memory helpers
+ * (so that hosts without torch can still hold results in HBM) */
+int  smm_device_malloc(smm_ctx *ctx, int64_t bytes, void **d_ptr);
+int  smm_device_free(smm_ctx *ctx, void *d_ptr);
+int  smm_memcpy_d2h(smm_ctx *ctx, void *dst_host, const void *src_dev, int64_t bytes);
+int  smm_memcpy_h2d(smm_ctx *ctx, void *dst_dev, const void *src_host, int64_t bytes);
+
+/* ================================================================== LEGACY ABI
+ * Binary drop-in for the library the reference's unmodified matrix_ops.py loads
+ * (lib/libsparse*.so, matrix_ops.py:118-136).  Layouts as that file declares them. */
+struct sparsemat {                 /* matrix_ops.py:26-33 */
+    int nzmax, rows, cols;
+    int *rowPtr;
+    int *colInd;
+    double *values;
+};
+struct darray {                    /* matrix_ops.py:44-48 */
+    double *array;
+    int rows, cols;
+};
+struct iarray {                    /* include/matrix_def.h:34-38 with int dims */
+    int *array;
+    int rows, cols;
+};
+
+struct sparsemat *create_sparsemat(int rows, int cols, int nzmax);   /* memfunctions.cpp:117-131 */
+struct darray    *create_darray(int rows, int cols);                 /* memfunctions.cpp:143-154 */
+void destroy_sparsemat(struct sparsemat *m);                         /* memfunctions.cpp:22-33   */
+void destroy_darray(struct darray *m);                               /* memfunctions.cpp:51-57   */
+void destroy_iarray(struct iarray *m);                               /* memfunctions.cpp:37-43   */
+void modifyalloc(struct sparsemat *m, int new_size);                 /* memfunctions.cpp:77-103  */
+void limits(int tcov_rows, int numprocs, struct iarray *result);     /* workdivision.cpp:16-89   */
+/* imemSize is the reference's CPU scratch hint (sparse_sparse_sparse.cpp:204-217); it has
+ * no meaning on the GPU and is accepted and ignored.  On failure the output struct is left
+ * with nzmax==0 / NULL arrays and a message goes to stderr, as the reference does. */
+void sparse_nosym(const struct sparsemat *a, const struct sparsemat *b, struct sparsemat *c, int imemSize);
+void sparse_sym(const struct sparsemat *a, const struct sparsemat *b, struct sparsemat *c, int imemSize);
+void sparsework_nosym(const struct sparsemat *a, const struct sparsemat *b, struct sparsemat *c,
+                      int startIndex, int endIndex, int memIncrease);   /* sparsework.cpp:12-149  */
+void sparsework_sym(const struct sparsemat *a, const struct sparsemat *b, struct sparsemat *c,
+                    int startIndex, int endIndex, int memIncrease);     /* sparsework.cpp:156-300 */
+void dense_nosym(const struct sparsemat *a, const struct sparsemat *b, struct darray *c);
+void dense_sym(const struct sparsemat *a, const struct sparsemat *b, struct darray *c);
+void triple_product(struct sparsemat *h, struct sparsemat *q, struct darray *c, int compute_full_matrix);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMM_HIP_H */

@@ -1,0 +1,11 @@
+"""sparse_matrix_mult_amd -- MI355X (gfx950) engine behind sparse_matrix_multiply().
+
+    from sparse_matrix_mult_amd import sparse_matrix_multiply        # reference __init__.py:1-3
+
+The package holds only the hot path named in SURVEY.md section 8: the ctypes mirror of the
+reference's Python API (matrix_ops.py), an object layer over the C ABI (engine.py), the
+row-sharded multi-GPU driver (distributed.py) and the HIP sources (csrc/).
+"""
+from .matrix_ops import sparse_matrix_multiply
+
+__all__ = ['sparse_matrix_multiply']

@@ -1,0 +1,116 @@
+"""ctypes loader of lib/libsmm_hip.so -- the only native code this package uses.
+
+Mirrors MatrixOpsLibrary of the reference (sparse_matrix_mult/matrix_ops.py:51-184): a
+process-wide singleton that loads the shared library once and declares the prototypes.
+Unlike the reference it is silent at import (SURVEY F9 / section 8b "Side effects") and it
+refuses to run without the HIP library: there is no CPU fallback in this package.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsmm_hip.so")
+
+SMM_SYMMETRIC = 1
+SMM_FULL_MATRIX = 2
+SMM_UNORDERED = 4
+
+_c_i64 = ctypes.c_int64
+_vp = ctypes.c_void_p
+_pp = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> (restype, argtypes); every v2 symbol declared in include/smm_hip.h
+V2_PROTOTYPES = {
+    "smm_device_count": (ctypes.c_int, []),
+    "smm_last_error": (ctypes.c_char_p, []),
+    "smm_ctx_create": (ctypes.c_int, [ctypes.c_int, _vp, _pp]),
+    "smm_ctx_destroy": (None, [_vp]),
+    "smm_ctx_synchronize": (ctypes.c_int, [_vp]),
+    "smm_ctx_timing": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "smm_ctx_timing_reset": (ctypes.c_int, [_vp]),
+    "smm_ctx_kernel_time": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
+                                           ctypes.POINTER(_c_i64)]),
+    "smm_ctx_tune": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    "smm_csr_from_host": (ctypes.c_int, [_vp, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _pp]),
+    "smm_csr_from_device": (ctypes.c_int, [_vp, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _pp]),
+    "smm_csr_destroy": (None, [_vp]),
+    "smm_csr_rows": (_c_i64, [_vp]),
+    "smm_csr_cols": (_c_i64, [_vp]),
+    "smm_csr_nnz": (_c_i64, [_vp]),
+    "smm_csr_is_canonical": (ctypes.c_int, [_vp, _vp]),
+    "smm_row_products": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "smm_spgemm_symbolic": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _c_i64, _pp, ctypes.POINTER(_c_i64)]),
+    "smm_spgemm_numeric": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "smm_spgemm_numeric_host": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "smm_plan_indptr_host": (ctypes.c_int, [_vp, _vp, _vp]),
+    "smm_plan_nnz": (_c_i64, [_vp]),
+    "smm_plan_destroy": (None, [_vp]),
+    "smm_spgemm_dense": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _c_i64, _vp]),
+    "smm_spgemm_dense_host": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _c_i64, _vp]),
+    "smm_triple_product": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _c_i64, _c_i64, _vp]),
+    "smm_triple_product_host": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _c_i64, _c_i64, _vp]),
+    "smm_device_malloc": (ctypes.c_int, [_vp, _c_i64, _pp]),
+    "smm_device_free": (ctypes.c_int, [_vp, _vp]),
+    "smm_memcpy_d2h": (ctypes.c_int, [_vp, _vp, _vp, _c_i64]),
+    "smm_memcpy_h2d": (ctypes.c_int, [_vp, _vp, _vp, _c_i64]),
+}
+
+# the legacy symbols the reference's own matrix_ops.py binds (matrix_ops.py:147-171) plus the
+# rest of include/functions.h:43-84
+LEGACY_SYMBOLS = [
+    "create_sparsemat", "create_darray", "destroy_sparsemat", "destroy_darray", "destroy_iarray",
+    "modifyalloc", "limits", "sparse_nosym", "sparse_sym", "sparsework_nosym", "sparsework_sym",
+    "dense_nosym", "dense_sym", "triple_product",
+]
+
+
+class SmmError(RuntimeError):
+    """A call into libsmm_hip.so failed; .code is the negative smm_status."""
+
+    def __init__(self, code, message):
+        super().__init__(f"libsmm_hip error {code}: {message}")
+        self.code = code
+
+
+def build(force=False):
+    """Compile lib/libsmm_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-s", "-C", os.path.join(_HERE, "csrc")]
+    if force:
+        args.append("-B")
+    subprocess.run(args, check=True)
+
+
+class SmmLibrary:
+    """Singleton holding the loaded library (reference MatrixOpsLibrary, matrix_ops.py:51-72)."""
+    _instance = None
+    _lock = threading.Lock()
+
+    def __new__(cls):
+        with cls._lock:
+            if cls._instance is None:
+                inst = super().__new__(cls)
+                inst._lib = None
+                cls._instance = inst
+        return cls._instance
+
+    def get_lib(self):
+        if self._lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise OSError(
+                    f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "or `make -C sparse_matrix_mult_amd/csrc`. This package has no CPU fallback.")
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in V2_PROTOTYPES.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            self._lib = lib
+        return self._lib
+
+
+def check(lib, rc):
+    if rc != 0:
+        msg = lib.smm_last_error()
+        raise SmmError(rc, msg.decode("utf-8", "replace") if msg else "unknown error")

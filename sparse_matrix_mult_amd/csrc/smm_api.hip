@@ -1,0 +1,806 @@
+// smm_api.hip -- host side of libsmm_hip.so: the v2 C ABI declared in include/smm_hip.h.
+// Owns the device context (stream, pooled workspace, per-kernel timing) and sequences the
+// kernels of smm_kernels.hpp.  There is deliberately no CPU compute path in this file: with
+// no device every entry point fails with SMM_ERR_NO_DEVICE.
+#include "smm_kernels.hpp"
+#include "../../include/smm_hip.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace smm;
+
+// ------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(SMM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                \
+    } while (0)
+#define CHK(expr)                      \
+    do {                               \
+        int rc_ = (expr);              \
+        if (rc_ != SMM_OK) return rc_; \
+    } while (0)
+
+extern "C" const char *smm_last_error(void) { return g_err; }
+
+extern "C" int smm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+// ------------------------------------------------------------------------------ context
+struct PoolBlock { void *p; size_t bytes; };
+struct TimedLaunch { std::string name; hipEvent_t t0, t1; };
+
+struct smm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool timing = false;
+    int lds_cols = 8192;     // accumulator columns per workgroup (x8 B of LDS)
+    int waves = 4;           // waves per numeric workgroup
+    int n_cu = 256;
+    std::vector<PoolBlock> pool;          // free blocks
+    std::map<void *, size_t> live;        // blocks handed out
+    std::vector<TimedLaunch> launches;
+    std::map<std::string, std::pair<double, int64_t>> totals;
+    unsigned *d_flags = nullptr;
+    std::mutex mu;
+};
+
+static int pool_alloc(smm_ctx *c, size_t bytes, void **out)
+{
+    if (bytes == 0) bytes = 16;
+    bytes = (bytes + 255) & ~(size_t)255;
+    int best = -1;
+    for (int i = 0; i < (int)c->pool.size(); ++i)
+        if (c->pool[i].bytes >= bytes && c->pool[i].bytes <= bytes + bytes / 4 + (1 << 20) &&
+            (best < 0 || c->pool[i].bytes < c->pool[best].bytes))
+            best = i;
+    if (best >= 0) {
+        *out = c->pool[best].p;
+        c->live[*out] = c->pool[best].bytes;
+        c->pool.erase(c->pool.begin() + best);
+        return SMM_OK;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        // drop the cache and retry once
+        for (auto &b : c->pool) (void)hipFree(b.p);
+        c->pool.clear();
+        (void)hipGetLastError();
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(SMM_ERR_ALLOC, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        }
+    }
+    c->live[p] = bytes;
+    *out = p;
+    return SMM_OK;
+}
+static void pool_free(smm_ctx *c, void *p)
+{
+    if (!p) return;
+    auto it = c->live.find(p);
+    if (it == c->live.end()) return;
+    c->pool.push_back({p, it->second});
+    c->live.erase(it);
+}
+template <typename T> static int pool_get(smm_ctx *c, size_t count, T **out)
+{
+    void *p = nullptr;
+    int rc = pool_alloc(c, count * sizeof(T), &p);
+    *out = (T *)p;
+    return rc;
+}
+
+struct LaunchTimer {
+    smm_ctx *c; const char *name; hipEvent_t t0 = nullptr, t1 = nullptr;
+    LaunchTimer(smm_ctx *ctx, const char *n) : c(ctx), name(n)
+    {
+        if (c->timing) {
+            (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
+            (void)hipEventRecord(t0, c->stream);
+        }
+    }
+    ~LaunchTimer()
+    {
+        if (c->timing) {
+            (void)hipEventRecord(t1, c->stream);
+            c->launches.push_back({name, t0, t1});
+        }
+    }
+};
+#define LAUNCH(ctx, name, kern, grid, block, lds, ...)                                         \
+    do {                                                                                       \
+        LaunchTimer lt_(ctx, name);                                                            \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (size_t)(lds), \
+                           (ctx)->stream, __VA_ARGS__);                                        \
+    } while (0)
+#define LAUNCH_CHECK() HIPCHK(hipGetLastError())
+
+extern "C" int smm_ctx_create(int device, void *hip_stream, smm_ctx **out)
+{
+    if (!out) return fail(SMM_ERR_INVALID, "smm_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = smm_device_count();
+    if (n <= 0) return fail(SMM_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= n) return fail(SMM_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SMM_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device,
+                    prop.gcnArchName);
+    smm_ctx *c = new smm_ctx();
+    c->device = device;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+    else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return fail(SMM_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        c->own_stream = true;
+    }
+    if (hipMalloc((void **)&c->d_flags, 256) != hipSuccess) { delete c; return fail(SMM_ERR_ALLOC, "hipMalloc flags"); }
+    *out = c;
+    return SMM_OK;
+}
+
+extern "C" void smm_ctx_destroy(smm_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &l : c->launches) { (void)hipEventDestroy(l.t0); (void)hipEventDestroy(l.t1); }
+    for (auto &b : c->pool) (void)hipFree(b.p);
+    for (auto &kv : c->live) (void)hipFree(kv.first);
+    (void)hipFree(c->d_flags);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int smm_ctx_synchronize(smm_ctx *c)
+{
+    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SMM_OK;
+}
+
+static int drain_timers(smm_ctx *c)
+{
+    if (c->launches.empty()) return SMM_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto &l : c->launches) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, l.t0, l.t1);
+        auto &t = c->totals[l.name];
+        t.first += ms; t.second += 1;
+        (void)hipEventDestroy(l.t0); (void)hipEventDestroy(l.t1);
+    }
+    c->launches.clear();
+    return SMM_OK;
+}
+extern "C" int smm_ctx_timing(smm_ctx *c, int enable)
+{
+    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CHK(drain_timers(c));
+    c->timing = enable != 0;
+    return SMM_OK;
+}
+extern "C" int smm_ctx_timing_reset(smm_ctx *c)
+{
+    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CHK(drain_timers(c));
+    c->totals.clear();
+    return SMM_OK;
+}
+extern "C" int smm_ctx_kernel_time(smm_ctx *c, const char *kernel, double *ms_total, int64_t *launches)
+{
+    if (!c || !kernel) return fail(SMM_ERR_INVALID, "smm_ctx_kernel_time: NULL argument");
+    CHK(drain_timers(c));
+    auto it = c->totals.find(kernel);
+    if (ms_total) *ms_total = it == c->totals.end() ? 0.0 : it->second.first;
+    if (launches) *launches = it == c->totals.end() ? 0 : it->second.second;
+    return SMM_OK;
+}
+extern "C" int smm_ctx_tune(smm_ctx *c, int lds_cols, int waves)
+{
+    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    if (lds_cols) {
+        if (lds_cols < 256 || lds_cols > 16384) return fail(SMM_ERR_INVALID, "lds_cols must be in [256,16384]");
+        c->lds_cols = lds_cols;
+    }
+    if (waves) {
+        if (waves != 4 && waves != 8) return fail(SMM_ERR_INVALID, "waves must be 4 or 8");
+        c->waves = waves;
+    }
+    return SMM_OK;
+}
+
+// ------------------------------------------------------------------------------ operands
+struct smm_csr {
+    smm_ctx *ctx = nullptr;
+    int64_t rows = 0, cols = 0, nnz = 0;
+    const int *ptr = nullptr, *idx = nullptr;
+    const double *val = nullptr;
+    bool owned = false;
+    bool validated = false;
+    unsigned vflags = 0;
+    // cached tile index (sorted operands only)
+    int *seg = nullptr; int seg_wf = 0, seg_nft = 0;
+};
+
+static int validate(smm_ctx *c, smm_csr *m)
+{
+    if (m->validated) return (m->vflags & CSR_BAD) ? fail(SMM_ERR_INVALID, "malformed CSR operand") : SMM_OK;
+    HIPCHK(hipMemsetAsync(c->d_flags, 0, sizeof(unsigned), c->stream));
+    const int grid = (int)std::min<int64_t>(std::max<int64_t>((m->rows + 3) / 4, 1), 8192);
+    LAUNCH(c, "smm_validate", smm_validate, grid, 256, 0, (int)m->rows, (int)m->cols, (int)m->nnz, m->ptr, m->idx,
+           c->d_flags);
+    LAUNCH_CHECK();
+    unsigned f = 0;
+    HIPCHK(hipMemcpyAsync(&f, c->d_flags, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    m->vflags = f;
+    m->validated = true;
+    if (f & CSR_BAD)
+        return fail(SMM_ERR_INVALID, "malformed CSR operand (non-monotone indptr or column index out of range)");
+    return SMM_OK;
+}
+
+static int csr_common(smm_ctx *c, int64_t rows, int64_t cols, int64_t nnz)
+{
+    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    if (rows < 0 || cols < 0 || nnz < 0) return fail(SMM_ERR_INVALID, "negative dimension");
+    if (rows >= INT32_MAX || cols >= INT32_MAX || nnz >= INT32_MAX)
+        return fail(SMM_ERR_INVALID, "operand dimensions/nnz must be < 2^31 (int32 indices, as the reference)");
+    HIPCHK(hipSetDevice(c->device));
+    return SMM_OK;
+}
+
+extern "C" int smm_csr_from_host(smm_ctx *c, int64_t rows, int64_t cols, int64_t nnz, const int32_t *indptr,
+                                 const int32_t *indices, const double *data, smm_csr **out)
+{
+    if (!out) return fail(SMM_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    CHK(csr_common(c, rows, cols, nnz));
+    if (!indptr || (nnz > 0 && (!indices || !data))) return fail(SMM_ERR_INVALID, "NULL CSR array");
+    int *dp = nullptr, *di = nullptr; double *dv = nullptr;
+    if (hipMalloc((void **)&dp, (rows + 1) * sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&di, std::max<int64_t>(nnz, 1) * sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&dv, std::max<int64_t>(nnz, 1) * sizeof(double)) != hipSuccess) {
+        (void)hipFree(dp); (void)hipFree(di); (void)hipFree(dv);
+        return fail(SMM_ERR_ALLOC, "hipMalloc of a CSR operand failed");
+    }
+    HIPCHK(hipMemcpyAsync(dp, indptr, (rows + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (nnz > 0) {
+        HIPCHK(hipMemcpyAsync(di, indices, nnz * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(dv, data, nnz * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    smm_csr *m = new smm_csr();
+    m->ctx = c; m->rows = rows; m->cols = cols; m->nnz = nnz;
+    m->ptr = dp; m->idx = di; m->val = dv; m->owned = true;
+    int rc = validate(c, m);
+    if (rc != SMM_OK) { smm_csr_destroy(m); return rc; }
+    *out = m;
+    return SMM_OK;
+}
+
+extern "C" int smm_csr_from_device(smm_ctx *c, int64_t rows, int64_t cols, int64_t nnz, const int32_t *d_indptr,
+                                   const int32_t *d_indices, const double *d_data, smm_csr **out)
+{
+    if (!out) return fail(SMM_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    CHK(csr_common(c, rows, cols, nnz));
+    if (!d_indptr || (nnz > 0 && (!d_indices || !d_data))) return fail(SMM_ERR_INVALID, "NULL CSR array");
+    smm_csr *m = new smm_csr();
+    m->ctx = c; m->rows = rows; m->cols = cols; m->nnz = nnz;
+    m->ptr = d_indptr; m->idx = d_indices; m->val = d_data; m->owned = false;
+    int rc = validate(c, m);
+    if (rc != SMM_OK) { delete m; return rc; }
+    *out = m;
+    return SMM_OK;
+}
+
+extern "C" void smm_csr_destroy(smm_csr *m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    if (m->owned) { (void)hipFree((void *)m->ptr); (void)hipFree((void *)m->idx); (void)hipFree((void *)m->val); }
+    if (m->seg) (void)hipFree(m->seg);
+    delete m;
+}
+extern "C" int64_t smm_csr_rows(const smm_csr *m) { return m ? m->rows : -1; }
+extern "C" int64_t smm_csr_cols(const smm_csr *m) { return m ? m->cols : -1; }
+extern "C" int64_t smm_csr_nnz(const smm_csr *m) { return m ? m->nnz : -1; }
+extern "C" int smm_csr_is_canonical(smm_ctx *c, smm_csr *m)
+{
+    if (!c || !m) return fail(SMM_ERR_INVALID, "NULL argument");
+    CHK(validate(c, m));
+    return (m->vflags & (CSR_UNSORTED | CSR_HAS_EQUAL)) ? 0 : 1;
+}
+
+// Tile geometry: nct coarse tiles of wc = nw*wf columns; fine tile t covers [t*wf,(t+1)*wf).
+struct Geom { int nct, wc, wf, n_ft, nw; };
+static Geom make_geom(const smm_ctx *c, int64_t ncols)
+{
+    Geom g;
+    g.nw = c->waves;
+    const int64_t cols = std::max<int64_t>(ncols, 1);
+    g.nct = (int)((cols + c->lds_cols - 1) / c->lds_cols);
+    const int64_t per = (cols + g.nct - 1) / g.nct;
+    g.wf = (int)((per + g.nw - 1) / g.nw);
+    g.wc = g.wf * g.nw;
+    g.n_ft = g.nct * g.nw;
+    return g;
+}
+
+static int ensure_seg(smm_ctx *c, smm_csr *b, const Geom &g)
+{
+    if (b->seg && b->seg_wf == g.wf && b->seg_nft == g.n_ft) return SMM_OK;
+    if (b->seg) { HIPCHK(hipStreamSynchronize(c->stream)); (void)hipFree(b->seg); b->seg = nullptr; }
+    const int64_t total = b->rows * (int64_t)(g.n_ft + 1);
+    if (hipMalloc((void **)&b->seg, std::max<int64_t>(total, 1) * sizeof(int)) != hipSuccess)
+        return fail(SMM_ERR_ALLOC, "hipMalloc of the tile index failed");
+    if (total > 0) {
+        LAUNCH(c, "smm_segptr", smm_segptr, (total + 255) / 256, 256, 0, (int)b->rows, g.n_ft, g.wf, b->ptr, b->idx,
+               b->seg);
+        LAUNCH_CHECK();
+    }
+    b->seg_wf = g.wf; b->seg_nft = g.n_ft;
+    return SMM_OK;
+}
+
+static int check_pair(smm_ctx *c, smm_csr *a, smm_csr *b)
+{
+    if (!c || !a || !b) return fail(SMM_ERR_INVALID, "NULL argument");
+    if (a->ctx != c || b->ctx != c) return fail(SMM_ERR_INVALID, "operand belongs to another context");
+    if (a->cols != b->rows)       /* matrix_ops.py:312-313, sparse_sparse_dense.cpp:83-86 */
+        return fail(SMM_ERR_INVALID, "Matrix dimensions are incompatible for multiplication (%lld x %lld times %lld x %lld)",
+                    (long long)a->rows, (long long)a->cols, (long long)b->rows, (long long)b->cols);
+    HIPCHK(hipSetDevice(c->device));
+    CHK(validate(c, a));
+    CHK(validate(c, b));
+    return SMM_OK;
+}
+
+extern "C" int smm_row_products(smm_ctx *c, const smm_csr *a, const smm_csr *b, int64_t *products_host)
+{
+    CHK(check_pair(c, (smm_csr *)a, (smm_csr *)b));
+    if (!products_host) return fail(SMM_ERR_INVALID, "products_host is NULL");
+    if (a->rows == 0) return SMM_OK;
+    int64_t *d = nullptr;
+    CHK(pool_get(c, (size_t)a->rows, &d));
+    const int grid = (int)std::min<int64_t>((a->rows + 3) / 4, 16384);
+    LAUNCH(c, "smm_row_work", smm_row_work, grid, 256, 0, (int)a->rows, (int)b->cols, (int64_t)0, 0, a->ptr, a->idx,
+           b->ptr, d, (int64_t *)nullptr);
+    LAUNCH_CHECK();
+    HIPCHK(hipMemcpyAsync(products_host, d, a->rows * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    pool_free(c, d);
+    return SMM_OK;
+}
+
+// ------------------------------------------------------------------------------ numeric dispatch
+template <int OUT, bool SYM, bool ORD, int NW>
+static int launch_numeric_t(smm_ctx *c, const NumericArgs &args, int64_t grid)
+{
+    const size_t lds = (size_t)args.wc * sizeof(double);
+    auto kern = smm_numeric<OUT, SYM, ORD, NW>;
+    if (lds > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    LAUNCH(c, OUT == OUT_SPARSE ? "smm_numeric" : "smm_numeric_dense", kern, grid, NW * 64, lds, args);
+    LAUNCH_CHECK();
+    return SMM_OK;
+}
+template <int OUT>
+static int launch_numeric(smm_ctx *c, const NumericArgs &args, bool sym, bool ordered, int nw)
+{
+    const int64_t grid = (int64_t)args.m * args.nct;
+    if (grid <= 0) return SMM_OK;
+    if (grid > 0x7fffffff) return fail(SMM_ERR_INVALID, "too many (row, tile) units for one launch");
+#define SMM_CASE(S, O, N) \
+    if (sym == S && ordered == O && nw == N) return launch_numeric_t<OUT, S, O, N>(c, args, grid);
+    SMM_CASE(false, false, 4) SMM_CASE(false, true, 4) SMM_CASE(true, false, 4) SMM_CASE(true, true, 4)
+    SMM_CASE(false, false, 8) SMM_CASE(false, true, 8) SMM_CASE(true, false, 8) SMM_CASE(true, true, 8)
+#undef SMM_CASE
+    return fail(SMM_ERR_INVALID, "unsupported numeric configuration");
+}
+
+// ------------------------------------------------------------------------------ CSR x CSR -> CSR
+struct smm_plan {
+    smm_ctx *ctx = nullptr;
+    smm_csr *a = nullptr, *b = nullptr;
+    int flags = 0;
+    int64_t row_offset = 0;
+    int64_t m = 0, ncols = 0, nnz = 0;
+    bool b_sorted = true;
+    Geom g{};
+    int64_t *d_ub_off = nullptr;   // m+1
+    int *d_tmp = nullptr;          // capacity-strided ordered column lists
+    unsigned *d_P = nullptr;       // nnz(A)
+    int *d_rowcnt = nullptr;       // m
+    int64_t *d_cptr = nullptr;     // m+1
+    unsigned *d_runs = nullptr;    // nnz(A) x (nct+1)
+};
+
+extern "C" void smm_plan_destroy(smm_plan *p)
+{
+    if (!p) return;
+    smm_ctx *c = p->ctx;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    pool_free(c, p->d_ub_off); pool_free(c, p->d_tmp); pool_free(c, p->d_P);
+    pool_free(c, p->d_rowcnt); pool_free(c, p->d_cptr); pool_free(c, p->d_runs);
+    delete p;
+}
+extern "C" int64_t smm_plan_nnz(const smm_plan *p) { return p ? p->nnz : -1; }
+
+template <bool SYM, bool SAFE, bool LDSBM>
+static int launch_symbolic_t(smm_ctx *c, smm_plan *p, int bm_words, unsigned *gbm, int grid)
+{
+    const size_t lds = LDSBM ? (size_t)bm_words * 4 * sizeof(unsigned) : 0;
+    auto kern = smm_symbolic<SYM, SAFE, LDSBM>;
+    if (lds > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    LAUNCH(c, "smm_symbolic", kern, grid, 256, lds, (int)p->m, p->row_offset, bm_words, p->a->ptr, p->a->idx,
+           p->b->ptr, p->b->idx, p->d_ub_off, p->d_tmp, p->d_P, p->d_rowcnt, gbm);
+    LAUNCH_CHECK();
+    return SMM_OK;
+}
+
+extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t a_row_offset,
+                                   smm_plan **plan, int64_t *nnz_out)
+{
+    if (!plan) return fail(SMM_ERR_INVALID, "plan is NULL");
+    *plan = nullptr;
+    CHK(check_pair(c, a, b));
+    if (a_row_offset < 0) return fail(SMM_ERR_INVALID, "negative a_row_offset");
+    std::lock_guard<std::mutex> lock(c->mu);
+    smm_plan *p = new smm_plan();
+    p->ctx = c; p->a = a; p->b = b; p->flags = flags; p->row_offset = a_row_offset;
+    p->m = a->rows; p->ncols = b->cols;
+    p->b_sorted = !(b->vflags & CSR_UNSORTED);
+    p->g = make_geom(c, p->ncols);
+    const bool sym = flags & SMM_SYMMETRIC;
+    const int64_t m = p->m;
+    int rc = SMM_OK;
+#define PCHK(expr) do { rc = (expr); if (rc != SMM_OK) { smm_plan_destroy(p); return rc; } } while (0)
+    PCHK(pool_get(c, (size_t)m + 1, &p->d_cptr));
+    if (m == 0 || a->nnz == 0 || b->nnz == 0 || p->ncols == 0) {
+        // sparse_sparse_sparse.cpp:181-185: zero operand -> rowPtr of zeros only
+        hipError_t e = hipMemsetAsync(p->d_cptr, 0, (m + 1) * sizeof(int64_t), c->stream);
+        if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "memset: %s", hipGetErrorString(e)); }
+        p->nnz = 0;
+        if (nnz_out) *nnz_out = 0;
+        *plan = p;
+        return SMM_OK;
+    }
+    // capacities of the per-row ordered lists
+    int64_t *d_prod = nullptr, *d_ub = nullptr;
+    PCHK(pool_get(c, (size_t)m, &d_prod));
+    PCHK(pool_get(c, (size_t)m, &d_ub));
+    PCHK(pool_get(c, (size_t)m + 1, &p->d_ub_off));
+    const int wgrid = (int)std::min<int64_t>((m + 3) / 4, 16384);
+    LAUNCH(c, "smm_row_work", smm_row_work, wgrid, 256, 0, (int)m, (int)p->ncols, p->row_offset, sym ? 1 : 0, a->ptr,
+           a->idx, b->ptr, d_prod, d_ub);
+    LAUNCH(c, "smm_scan", smm_scan<int64_t>, 1, 1024, 0, (int)m, (const int64_t *)d_ub, p->d_ub_off);
+    int64_t total_ub = 0;
+    {
+        hipError_t e = hipMemcpyAsync(&total_ub, p->d_ub_off + m, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "row work: %s", hipGetErrorString(e)); }
+    }
+    pool_free(c, d_prod); pool_free(c, d_ub);
+    PCHK(pool_get(c, (size_t)std::max<int64_t>(total_ub, 1), &p->d_tmp));
+    PCHK(pool_get(c, (size_t)a->nnz, &p->d_P));
+    PCHK(pool_get(c, (size_t)m, &p->d_rowcnt));
+
+    // symbolic: one wave per row, 4 rows per workgroup
+    const int bm_words = (int)((p->ncols + 31) / 32);
+    const bool ldsbm = (size_t)bm_words * 4 * sizeof(unsigned) <= 128 * 1024;
+    const bool safe = (b->vflags & (CSR_HAS_EQUAL | CSR_UNSORTED)) != 0;
+    int sgrid = (int)std::min<int64_t>((m + 3) / 4, (int64_t)c->n_cu * 8);
+    unsigned *gbm = nullptr;
+    if (!ldsbm) PCHK(pool_get(c, (size_t)sgrid * 4 * bm_words, &gbm));
+#define SYM_CASE(S, F, L) if (sym == S && safe == F && ldsbm == L) PCHK((launch_symbolic_t<S, F, L>(c, p, bm_words, gbm, sgrid)));
+    SYM_CASE(false, false, true) SYM_CASE(false, true, true) SYM_CASE(true, false, true) SYM_CASE(true, true, true)
+    SYM_CASE(false, false, false) SYM_CASE(false, true, false) SYM_CASE(true, false, false) SYM_CASE(true, true, false)
+#undef SYM_CASE
+    LAUNCH(c, "smm_scan", smm_scan<int>, 1, 1024, 0, (int)m, (const int *)p->d_rowcnt, p->d_cptr);
+    {
+        hipError_t e = hipMemcpyAsync(&p->nnz, p->d_cptr + m, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "symbolic phase: %s", hipGetErrorString(e)); }
+    }
+    if (gbm) pool_free(c, gbm);
+    if (p->b_sorted && p->nnz > 0) {
+        PCHK(ensure_seg(c, b, p->g));
+        PCHK(pool_get(c, (size_t)a->nnz * (p->g.nct + 1), &p->d_runs));
+        const int rgrid = (int)std::min<int64_t>((m + 3) / 4, 65536);
+        LAUNCH(c, "smm_runs", smm_runs, rgrid, 256, 0, (int)m, p->g.nct, p->g.wc, a->ptr, p->d_ub_off, p->d_rowcnt,
+               p->d_P, p->d_tmp, p->d_runs);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "smm_runs: %s", hipGetErrorString(e)); }
+    }
+#undef PCHK
+    if (nnz_out) *nnz_out = p->nnz;
+    *plan = p;
+    return SMM_OK;
+}
+
+extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, int32_t *d_c_indices, double *d_c_data)
+{
+    if (!c || !p || p->ctx != c) return fail(SMM_ERR_INVALID, "bad plan/context");
+    if (!d_c_indptr) return fail(SMM_ERR_INVALID, "d_c_indptr is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lock(c->mu);
+    const int64_t m = p->m;
+    HIPCHK(hipMemcpyAsync(d_c_indptr, p->d_cptr, (m + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
+    if (p->nnz == 0) return SMM_OK;
+    if (!d_c_indices || !d_c_data) return fail(SMM_ERR_INVALID, "output arrays are NULL but nnz > 0");
+    const bool sym = p->flags & SMM_SYMMETRIC;
+    const int cgrid = (int)std::min<int64_t>(m, 65536);
+    LAUNCH(c, "smm_compact", smm_compact, cgrid, 256, 0, (int)m, p->d_ub_off, p->d_cptr, p->d_tmp, d_c_indices);
+    LAUNCH_CHECK();
+    if (p->b_sorted) {
+        NumericArgs A{};
+        A.m = (int)m; A.ncols = (int)p->ncols; A.nct = p->g.nct; A.wc = p->g.wc; A.wf = p->g.wf; A.n_ft = p->g.n_ft;
+        A.row_offset = p->row_offset;
+        A.a_ptr = p->a->ptr; A.a_idx = p->a->idx; A.a_val = p->a->val;
+        A.b_idx = p->b->idx; A.b_val = p->b->val; A.seg = p->b->seg;
+        A.c_ptr = p->d_cptr; A.c_idx = d_c_indices; A.c_val = d_c_data; A.runs = p->d_runs;
+        CHK(launch_numeric<OUT_SPARSE>(c, A, sym, !(p->flags & SMM_UNORDERED), p->g.nw));
+    } else {
+        const int grid = (int)std::min<int64_t>((m + 3) / 4, (int64_t)c->n_cu * 2);
+        int *slot = nullptr;
+        CHK(pool_get(c, (size_t)grid * 4 * (size_t)p->ncols, &slot));
+        if (sym)
+            LAUNCH(c, "smm_numeric_general", smm_numeric_general<true>, grid, 256, 0, (int)m, (int)p->ncols,
+                   p->row_offset, p->a->ptr, p->a->idx, p->a->val, p->b->ptr, p->b->idx, p->b->val, p->d_cptr,
+                   d_c_indices, d_c_data, slot);
+        else
+            LAUNCH(c, "smm_numeric_general", smm_numeric_general<false>, grid, 256, 0, (int)m, (int)p->ncols,
+                   p->row_offset, p->a->ptr, p->a->idx, p->a->val, p->b->ptr, p->b->idx, p->b->val, p->d_cptr,
+                   d_c_indices, d_c_data, slot);
+        LAUNCH_CHECK();
+        HIPCHK(hipStreamSynchronize(c->stream));
+        pool_free(c, slot);
+    }
+    return SMM_OK;
+}
+
+extern "C" int smm_plan_indptr_host(smm_ctx *c, smm_plan *p, int64_t *c_indptr)
+{
+    if (!c || !p || !c_indptr) return fail(SMM_ERR_INVALID, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c_indptr, p->d_cptr, (p->m + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SMM_OK;
+}
+
+extern "C" int smm_spgemm_numeric_host(smm_ctx *c, smm_plan *p, int64_t *c_indptr, int32_t *c_indices, double *c_data)
+{
+    if (!c || !p || !c_indptr) return fail(SMM_ERR_INVALID, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    int64_t *dp = nullptr; int *di = nullptr; double *dv = nullptr;
+    const int64_t nnz = p->nnz;
+    CHK(pool_get(c, (size_t)p->m + 1, &dp));
+    int rc = pool_get(c, (size_t)std::max<int64_t>(nnz, 1), &di);
+    if (rc == SMM_OK) rc = pool_get(c, (size_t)std::max<int64_t>(nnz, 1), &dv);
+    if (rc == SMM_OK) rc = smm_spgemm_numeric(c, p, dp, di, dv);
+    if (rc == SMM_OK) {
+        hipError_t e = hipMemcpyAsync(c_indptr, dp, (p->m + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && nnz > 0) {
+            if (!c_indices || !c_data) rc = fail(SMM_ERR_INVALID, "output arrays are NULL but nnz > 0");
+            else {
+                e = hipMemcpyAsync(c_indices, di, nnz * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(c_data, dv, nnz * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+            }
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess && rc == SMM_OK) rc = fail(SMM_ERR_HIP, "result download: %s", hipGetErrorString(e));
+    }
+    (void)hipStreamSynchronize(c->stream);
+    pool_free(c, dp); pool_free(c, di); pool_free(c, dv);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------ CSR x CSR -> dense
+static int dense_into(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t row_offset, double *d_c, int64_t ldc)
+{
+    const int64_t m = a->rows, n = b->cols;
+    if (m == 0 || n == 0) return SMM_OK;
+    const bool sym = flags & SMM_SYMMETRIC;
+    if (a->nnz == 0 || b->nnz == 0) {
+        HIPCHK(hipMemset2DAsync(d_c, ldc * sizeof(double), 0, n * sizeof(double), m, c->stream));
+        return SMM_OK;
+    }
+    if (!(b->vflags & CSR_UNSORTED)) {
+        Geom g = make_geom(c, n);
+        CHK(ensure_seg(c, b, g));
+        NumericArgs A{};
+        A.m = (int)m; A.ncols = (int)n; A.nct = g.nct; A.wc = g.wc; A.wf = g.wf; A.n_ft = g.n_ft;
+        A.row_offset = row_offset;
+        A.a_ptr = a->ptr; A.a_idx = a->idx; A.a_val = a->val;
+        A.b_idx = b->idx; A.b_val = b->val; A.seg = b->seg;
+        A.c_dense = d_c; A.ldc = ldc;
+        CHK(launch_numeric<OUT_DENSE>(c, A, sym, !(flags & SMM_UNORDERED), g.nw));
+    } else {
+        const int grid = (int)std::min<int64_t>((m + 3) / 4, 65536);
+        if (sym)
+            LAUNCH(c, "smm_dense_general", smm_dense_general<true>, grid, 256, 0, (int)m, (int)n, row_offset, a->ptr,
+                   a->idx, a->val, b->ptr, b->idx, b->val, d_c, ldc);
+        else
+            LAUNCH(c, "smm_dense_general", smm_dense_general<false>, grid, 256, 0, (int)m, (int)n, row_offset, a->ptr,
+                   a->idx, a->val, b->ptr, b->idx, b->val, d_c, ldc);
+        LAUNCH_CHECK();
+    }
+    return SMM_OK;
+}
+
+extern "C" int smm_spgemm_dense(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t a_row_offset, double *d_c)
+{
+    CHK(check_pair(c, a, b));
+    if (!d_c && a->rows * b->cols > 0) return fail(SMM_ERR_INVALID, "d_c is NULL");
+    std::lock_guard<std::mutex> lock(c->mu);
+    return dense_into(c, a, b, flags, a_row_offset, d_c, b->cols);
+}
+
+extern "C" int smm_spgemm_dense_host(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t a_row_offset, double *out)
+{
+    CHK(check_pair(c, a, b));
+    const int64_t total = a->rows * b->cols;
+    if (total == 0) return SMM_OK;
+    if (!out) return fail(SMM_ERR_INVALID, "c is NULL");
+    double *d = nullptr;
+    CHK(pool_get(c, (size_t)total, &d));
+    int rc = smm_spgemm_dense(c, a, b, flags, a_row_offset, d);
+    if (rc == SMM_OK) {
+        hipError_t e = hipMemcpyAsync(out, d, total * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(SMM_ERR_HIP, "result download: %s", hipGetErrorString(e));
+    }
+    (void)hipStreamSynchronize(c->stream);
+    pool_free(c, d);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------ triple product
+extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags, int64_t row_begin, int64_t row_end,
+                                  double *d_c)
+{
+    CHK(check_pair(c, h, q));
+    if (q->rows != q->cols) return fail(SMM_ERR_INVALID, "Q must be square (K x K)");
+    const int64_t n = h->rows, K = h->cols;
+    if (row_begin < 0 || row_end > n || row_begin > row_end) return fail(SMM_ERR_INVALID, "bad row range");
+    const bool full = flags & SMM_FULL_MATRIX;
+    if (full && (row_begin != 0 || row_end != n))
+        return fail(SMM_ERR_INVALID, "SMM_FULL_MATRIX needs the whole row range [0,n)");
+    const int64_t nr = row_end - row_begin;
+    if (nr == 0 || n == 0) return SMM_OK;
+    if (!d_c) return fail(SMM_ERR_INVALID, "d_c is NULL");
+    if (h->vflags & CSR_UNSORTED)
+        return fail(SMM_ERR_INVALID, "triple product needs H with sorted column indices inside each row");
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (h->nnz == 0 || q->nnz == 0 || K == 0) {
+        HIPCHK(hipMemset2DAsync(d_c, n * sizeof(double), 0, n * sizeof(double), nr, c->stream));
+        return SMM_OK;
+    }
+    // stage 1: T = H[row_begin:row_end, :] * Q, dense nr x K (sparse_sparse_dense.cpp:187-198)
+    double *T = nullptr;
+    CHK(pool_get(c, (size_t)nr * K, &T));
+    smm_csr hv = *h;                       // row-range view of H (borrowed arrays)
+    hv.ptr = h->ptr + row_begin; hv.rows = nr; hv.owned = false; hv.seg = nullptr;
+    // indptr of the view is not rebased: kernels only use ptr[row], ptr[row+1] as absolute positions.
+    int rc = dense_into(c, &hv, q, 0, 0, T, K);
+    if (rc != SMM_OK) { pool_free(c, T); return rc; }
+    // stage 2
+    constexpr int R = 4, NW = 8;
+    const int chunk_cap = 16384 / R;       // 128 KB of LDS for R tile rows
+    const int nchunks = (int)((K + chunk_cap - 1) / chunk_cap);
+    const int chunk = (int)((K + nchunks - 1) / nchunks);
+    // H's tile index with tile width = chunk
+    Geom gh; gh.nw = 1; gh.nct = nchunks; gh.wf = chunk; gh.wc = chunk; gh.n_ft = nchunks;
+    rc = ensure_seg(c, h, gh);
+    if (rc != SMM_OK) { pool_free(c, T); return rc; }
+    TripleArgs A{};
+    A.n = (int)n; A.K = (int)K; A.nchunks = nchunks; A.chunk = chunk;
+    A.row_begin = row_begin; A.row_end = row_end; A.full = full ? 1 : 0;
+    A.h_ptr = h->ptr; A.h_idx = h->idx; A.h_val = h->val; A.hseg = h->seg;
+    A.T = T; A.C = d_c; A.ldc = n;
+    const size_t lds = (size_t)R * chunk * sizeof(double);
+    auto kern = smm_triple_stage2<R, NW>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { pool_free(c, T); return fail(SMM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e)); }
+    }
+    LAUNCH(c, "smm_triple_stage2", kern, (nr + R - 1) / R, NW * 64, lds, A);
+    if (full) LAUNCH(c, "smm_triple_mirror", smm_triple_mirror, (n * n + 255) / 256, 256, 0, (int)n, d_c, n);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // T returns to the pool below
+    pool_free(c, T);
+    if (e != hipSuccess) return fail(SMM_ERR_HIP, "triple product: %s", hipGetErrorString(e));
+    return SMM_OK;
+}
+
+extern "C" int smm_triple_product_host(smm_ctx *c, smm_csr *h, smm_csr *q, int flags, int64_t row_begin,
+                                       int64_t row_end, double *out)
+{
+    if (!c || !h || !q) return fail(SMM_ERR_INVALID, "NULL argument");
+    const int64_t n = h->rows, nr = row_end - row_begin;
+    if (nr <= 0 || n == 0) return smm_triple_product(c, h, q, flags, row_begin, row_end, nullptr);
+    if (!out) return fail(SMM_ERR_INVALID, "c is NULL");
+    double *d = nullptr;
+    CHK(pool_get(c, (size_t)nr * n, &d));
+    int rc = smm_triple_product(c, h, q, flags, row_begin, row_end, d);
+    if (rc == SMM_OK) {
+        hipError_t e = hipMemcpyAsync(out, d, nr * n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(SMM_ERR_HIP, "result download: %s", hipGetErrorString(e));
+    }
+    (void)hipStreamSynchronize(c->stream);
+    pool_free(c, d);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------ memory helpers
+extern "C" int smm_device_malloc(smm_ctx *c, int64_t bytes, void **d_ptr)
+{
+    if (!c || !d_ptr || bytes < 0) return fail(SMM_ERR_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    hipError_t e = hipMalloc(d_ptr, (size_t)std::max<int64_t>(bytes, 16));
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(SMM_ERR_ALLOC, "hipMalloc(%lld): %s", (long long)bytes, hipGetErrorString(e)); }
+    return SMM_OK;
+}
+extern "C" int smm_device_free(smm_ctx *c, void *d_ptr)
+{
+    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipFree(d_ptr));
+    return SMM_OK;
+}
+extern "C" int smm_memcpy_d2h(smm_ctx *c, void *dst, const void *src, int64_t bytes)
+{
+    if (!c || bytes < 0) return fail(SMM_ERR_INVALID, "bad argument");
+    if (bytes == 0) return SMM_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SMM_OK;
+}
+extern "C" int smm_memcpy_h2d(smm_ctx *c, void *dst, const void *src, int64_t bytes)
+{
+    if (!c || bytes < 0) return fail(SMM_ERR_INVALID, "bad argument");
+    if (bytes == 0) return SMM_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SMM_OK;
+}

@@ -1,0 +1,216 @@
+"""Thin object layer over the v2 C ABI (include/smm_hip.h): context, HBM-resident CSR
+operands, and the three products.  All arithmetic happens in libsmm_hip.so on the GPU; this
+module only moves pointers and sizes (numpy for host buffers, torch tensors -- optional --
+for device buffers and streams).
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+from ._lib import (SMM_FULL_MATRIX, SMM_SYMMETRIC, SMM_UNORDERED, SmmError, SmmLibrary, check)
+
+__all__ = ["Context", "DeviceCSR", "default_context", "SmmError",
+           "SMM_SYMMETRIC", "SMM_FULL_MATRIX", "SMM_UNORDERED"]
+
+
+def _ptr(arr):
+    return ctypes.c_void_p(arr.ctypes.data) if arr is not None and arr.size else ctypes.c_void_p(0)
+
+
+class Context:
+    """One GPU + one stream + pooled workspace (smm_ctx).  `stream` may be a raw hipStream_t
+    (int), e.g. torch.cuda.current_stream().cuda_stream; None lets the library create one."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = SmmLibrary().get_lib()
+        h = ctypes.c_void_p()
+        check(self.lib, self.lib.smm_ctx_create(int(device), ctypes.c_void_p(stream or 0), ctypes.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.smm_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(self.lib, self.lib.smm_ctx_synchronize(self.handle))
+
+    def tune(self, lds_cols=0, waves=0):
+        check(self.lib, self.lib.smm_ctx_tune(self.handle, int(lds_cols), int(waves)))
+
+    def timing(self, enable=True):
+        check(self.lib, self.lib.smm_ctx_timing(self.handle, 1 if enable else 0))
+
+    def timing_reset(self):
+        check(self.lib, self.lib.smm_ctx_timing_reset(self.handle))
+
+    def kernel_time(self, name):
+        """(total milliseconds, launches) of the named kernel since the last reset."""
+        ms, n = ctypes.c_double(), ctypes.c_int64()
+        check(self.lib, self.lib.smm_ctx_kernel_time(self.handle, name.encode(), ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    # ------------------------------------------------------------------ operands
+    def csr_from_scipy(self, m):
+        """Upload a scipy CSR matrix with the reference's casts (matrix_ops.py:196-198)."""
+        indptr = np.ascontiguousarray(m.indptr, dtype=np.int32)
+        indices = np.ascontiguousarray(m.indices, dtype=np.int32)
+        data = np.ascontiguousarray(m.data, dtype=np.float64)
+        return self.csr_from_arrays(m.shape[0], m.shape[1], indptr, indices, data)
+
+    def csr_from_arrays(self, rows, cols, indptr, indices, data):
+        assert indptr.dtype == np.int32 and indices.dtype == np.int32 and data.dtype == np.float64
+        nnz = int(indptr[-1]) if len(indptr) else 0
+        h = ctypes.c_void_p()
+        check(self.lib, self.lib.smm_csr_from_host(self.handle, rows, cols, nnz, _ptr(indptr), _ptr(indices),
+                                                   _ptr(data), ctypes.byref(h)))
+        return DeviceCSR(self, h, rows, cols, nnz)
+
+    def csr_from_torch(self, rows, cols, indptr, indices, data):
+        """Borrow int32/int32/float64 CUDA tensors already in HBM (kept alive by the handle)."""
+        nnz = int(indices.numel())
+        h = ctypes.c_void_p()
+        check(self.lib, self.lib.smm_csr_from_device(self.handle, rows, cols, nnz, ctypes.c_void_p(indptr.data_ptr()),
+                                                     ctypes.c_void_p(indices.data_ptr()),
+                                                     ctypes.c_void_p(data.data_ptr()), ctypes.byref(h)))
+        out = DeviceCSR(self, h, rows, cols, nnz)
+        out._keep = (indptr, indices, data)
+        return out
+
+    def row_products(self, a, b):
+        out = np.zeros(a.rows, dtype=np.int64)
+        check(self.lib, self.lib.smm_row_products(self.handle, a.handle, b.handle, _ptr(out)))
+        return out
+
+    # ------------------------------------------------------------------ CSR x CSR -> CSR
+    def spgemm_plan(self, a, b, symmetric=False, unordered=False, row_offset=0):
+        flags = (SMM_SYMMETRIC if symmetric else 0) | (SMM_UNORDERED if unordered else 0)
+        plan, nnz = ctypes.c_void_p(), ctypes.c_int64()
+        check(self.lib, self.lib.smm_spgemm_symbolic(self.handle, a.handle, b.handle, flags, int(row_offset),
+                                                     ctypes.byref(plan), ctypes.byref(nnz)))
+        return Plan(self, plan, a, b, nnz.value)
+
+    def spgemm_host(self, a, b, symmetric=False, unordered=False, row_offset=0):
+        """(indptr int64, indices int32, data float64) numpy arrays, reference (first-touch) order."""
+        plan = self.spgemm_plan(a, b, symmetric, unordered, row_offset)
+        try:
+            indptr = np.empty(a.rows + 1, dtype=np.int64)
+            indices = np.empty(plan.nnz, dtype=np.int32)
+            data = np.empty(plan.nnz, dtype=np.float64)
+            check(self.lib, self.lib.smm_spgemm_numeric_host(self.handle, plan.handle, _ptr(indptr), _ptr(indices),
+                                                             _ptr(data)))
+        finally:
+            plan.close()
+        return indptr, indices, data
+
+    def spgemm_torch(self, a, b, symmetric=False, unordered=False, row_offset=0):
+        """Same product with the result left in HBM as torch tensors (indptr int64)."""
+        import torch
+        plan = self.spgemm_plan(a, b, symmetric, unordered, row_offset)
+        try:
+            dev = torch.device("cuda", self.device)
+            indptr = torch.empty(a.rows + 1, dtype=torch.int64, device=dev)
+            indices = torch.empty(plan.nnz, dtype=torch.int32, device=dev)
+            data = torch.empty(plan.nnz, dtype=torch.float64, device=dev)
+            plan.numeric_into(indptr.data_ptr(), indices.data_ptr(), data.data_ptr())
+        finally:
+            plan.close()
+        return indptr, indices, data
+
+    # ------------------------------------------------------------------ CSR x CSR -> dense
+    def dense_host(self, a, b, symmetric=False, unordered=False, row_offset=0):
+        flags = (SMM_SYMMETRIC if symmetric else 0) | (SMM_UNORDERED if unordered else 0)
+        out = np.empty((a.rows, b.cols), dtype=np.float64)
+        check(self.lib, self.lib.smm_spgemm_dense_host(self.handle, a.handle, b.handle, flags, int(row_offset),
+                                                       _ptr(out)))
+        return out
+
+    def dense_into(self, a, b, d_ptr, symmetric=False, unordered=False, row_offset=0):
+        flags = (SMM_SYMMETRIC if symmetric else 0) | (SMM_UNORDERED if unordered else 0)
+        check(self.lib, self.lib.smm_spgemm_dense(self.handle, a.handle, b.handle, flags, int(row_offset),
+                                                  ctypes.c_void_p(d_ptr)))
+
+    # ------------------------------------------------------------------ H Q H^T
+    def triple_host(self, h, q, full=False, row_begin=0, row_end=None):
+        row_end = h.rows if row_end is None else row_end
+        out = np.empty((row_end - row_begin, h.rows), dtype=np.float64)
+        check(self.lib, self.lib.smm_triple_product_host(self.handle, h.handle, q.handle,
+                                                         SMM_FULL_MATRIX if full else 0, int(row_begin), int(row_end),
+                                                         _ptr(out)))
+        return out
+
+    def triple_into(self, h, q, d_ptr, full=False, row_begin=0, row_end=None):
+        row_end = h.rows if row_end is None else row_end
+        check(self.lib, self.lib.smm_triple_product(self.handle, h.handle, q.handle, SMM_FULL_MATRIX if full else 0,
+                                                    int(row_begin), int(row_end), ctypes.c_void_p(d_ptr)))
+
+
+class DeviceCSR:
+    def __init__(self, ctx, handle, rows, cols, nnz):
+        self.ctx, self.handle, self.rows, self.cols, self.nnz = ctx, handle, int(rows), int(cols), int(nnz)
+        self._keep = None
+
+    def is_canonical(self):
+        return bool(self.ctx.lib.smm_csr_is_canonical(self.ctx.handle, self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            self.ctx.lib.smm_csr_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Plan:
+    """Symbolic phase of one product (smm_plan): nnz and row pointer are known, the numeric
+    phase fills caller-owned buffers."""
+
+    def __init__(self, ctx, handle, a, b, nnz):
+        self.ctx, self.handle, self.a, self.b, self.nnz = ctx, handle, a, b, int(nnz)
+
+    def indptr_host(self):
+        out = np.empty(self.a.rows + 1, dtype=np.int64)
+        check(self.ctx.lib, self.ctx.lib.smm_plan_indptr_host(self.ctx.handle, self.handle, _ptr(out)))
+        return out
+
+    def numeric_into(self, d_indptr, d_indices, d_data):
+        check(self.ctx.lib, self.ctx.lib.smm_spgemm_numeric(self.ctx.handle, self.handle, ctypes.c_void_p(d_indptr),
+                                                            ctypes.c_void_p(d_indices), ctypes.c_void_p(d_data)))
+
+    def close(self):
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            self.ctx.lib.smm_plan_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default = None
+_default_lock = threading.Lock()
+
+
+def default_context():
+    """Process-wide context on the device of this rank (LOCAL_RANK, else SMM_DEVICE, else 0)."""
+    global _default
+    with _default_lock:
+        if _default is None:
+            dev = int(os.environ.get("SMM_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            _default = Context(dev)
+        return _default

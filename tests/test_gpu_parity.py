@@ -1,0 +1,201 @@
+"""Parity of the HIP path against the CPU oracle, through the C ABI (run on the MI355X box).
+
+Bar (north star / SURVEY 8a): indptr and indices bit-exact in the reference's first-touch
+order; float64 values bit-exact in the default (ordered) mode, within 1e-10 relative in
+SMM_UNORDERED mode.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from helpers import arrays, assert_csr_equal, rand_csr, rel_err, shuffle_rows, signed
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10   # north star: "float64 values within 1e-10 relative"
+
+CASES = [
+    # (m, k, n, dA, dB)
+    (1, 1, 1, 1.0, 1.0),
+    (7, 5, 9, 0.5, 0.5),
+    (64, 64, 64, 0.1, 0.1),
+    (130, 70, 257, 0.08, 0.05),
+    (500, 500, 500, 0.3, 0.3),          # reference tests/test_computation_speed.py:10-15
+    (500, 400, 500, 0.1, 0.1),          # reference tests/test_with_dense.py non-square case
+    (1000, 1000, 1000, 0.05, 0.05),     # BASELINE config 1
+    (300, 2000, 20000, 0.01, 0.004),    # several coarse tiles, long rows
+    (2000, 300, 40000, 0.02, 0.002),    # many tiles, short B rows
+]
+
+
+def _gpu_sparse(ctx, A, B, **kw):
+    a, b = ctx.csr_from_scipy(A), ctx.csr_from_scipy(B)
+    try:
+        return ctx.spgemm_host(a, b, **kw)
+    finally:
+        a.close(); b.close()
+
+
+@pytest.mark.parametrize("m,k,n,da,db", CASES)
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_sparse_matches_oracle(ctx, oracle, m, k, n, da, db, symmetric):
+    if symmetric and m != n:
+        pytest.skip("symmetric needs a square result")
+    A, B = rand_csr(m, k, da, 1), rand_csr(k, n, db, 2)
+    want = oracle.sparse(arrays(A), arrays(B), n, symmetric=symmetric)
+    got = _gpu_sparse(ctx, A, B, symmetric=symmetric)
+    assert_csr_equal(got, want, values="bits")
+    got_u = _gpu_sparse(ctx, A, B, symmetric=symmetric, unordered=True)
+    assert_csr_equal(got_u, want, values="tol", rtol=RTOL)
+
+
+@pytest.mark.parametrize("lds_cols,waves", [(256, 4), (512, 8), (8192, 8), (16384, 4), (16384, 8)])
+def test_sparse_tile_geometries(ctx, oracle, lds_cols, waves):
+    """Every tile geometry must give the same bits (tiles only change who adds, not the order)."""
+    A, B = signed(rand_csr(300, 400, 0.05, 3), 30), signed(rand_csr(400, 3000, 0.03, 4), 40)
+    want = oracle.sparse(arrays(A), arrays(B), 3000)
+    ctx.tune(lds_cols, waves)
+    try:
+        assert_csr_equal(_gpu_sparse(ctx, A, B), want, values="bits")
+        assert_csr_equal(_gpu_sparse(ctx, A, B, unordered=True), want, values="tol", rtol=1e-9)
+    finally:
+        ctx.tune(8192, 4)
+
+
+def test_sparse_structural_zeros_and_signed_zero(ctx, oracle):
+    """cancelled sums stay as explicit entries; -0.0 products keep their sign."""
+    A = sp.csr_matrix(np.array([[1.0, -1.0, 0.0], [0.0, 0.0, -2.0], [3.0, 0.0, 0.0]]))
+    B = sp.csr_matrix((np.array([1.0, 1.0, 0.0, 5.0]), np.array([0, 0, 1, 2]), np.array([0, 1, 2, 4])), shape=(3, 3))
+    want = oracle.sparse(arrays(A), arrays(B), 3)
+    got = _gpu_sparse(ctx, A, B)
+    assert_csr_equal(got, want, values="bits")
+    assert got[0][-1] == want[0][-1] == 4          # (0,0) cancels to 0.0 and is kept as an entry
+    assert got[2][0] == 0.0 and got[1][0] == 0
+    assert np.signbit(got[2][1]) and got[2][1] == 0.0   # -2 * 0.0 = -0.0 keeps its sign (first-touch store)
+
+
+def test_sparse_empty_rows_and_trailing_zero_rows(ctx, oracle):
+    """reference tests/test_edge_case.py:14-21,62-66: trailing all-zero rows."""
+    A = sp.csr_matrix(np.array([[1, 2, 3], [4, 5, 6], [7, 8, 9], [0, 0, 0], [0, 0, 0], [0, 0, 0]], dtype=float))
+    B = sp.csr_matrix(np.random.default_rng(0).random((3, 4)))
+    want = oracle.sparse(arrays(A), arrays(B), 4)
+    assert_csr_equal(_gpu_sparse(ctx, A, B), want, values="bits")
+    # empty rows in the middle of A and empty rows of B
+    A2 = rand_csr(200, 150, 0.02, 5); B2 = rand_csr(150, 180, 0.02, 6)
+    want = oracle.sparse(arrays(A2), arrays(B2), 180)
+    assert_csr_equal(_gpu_sparse(ctx, A2, B2), want, values="bits")
+
+
+def test_sparse_unsorted_and_duplicate_inputs(ctx, oracle):
+    """Non-canonical operands (reference matrix_ops.py:307-310 neither sorts nor dedups).
+    Unsorted B takes the general numeric path (global atomics): indices exact, values to
+    rounding.  Unsorted A only changes the order of the steps and stays bit-exact."""
+    A, B = rand_csr(150, 120, 0.1, 7), rand_csr(120, 400, 0.1, 8)
+    Au, Bu = shuffle_rows(A, 70), shuffle_rows(B, 80)
+    want = oracle.sparse(arrays(Au), arrays(B), 400)
+    assert_csr_equal(_gpu_sparse(ctx, Au, B), want, values="bits")
+    want = oracle.sparse(arrays(Au), arrays(Bu), 400)
+    assert_csr_equal(_gpu_sparse(ctx, Au, Bu), want, values="tol", rtol=RTOL)
+    want = oracle.sparse(arrays(Au), arrays(Bu), 400, symmetric=False)
+    # duplicates: repeat some entries of B's rows (sorted, repeated columns)
+    ip, ix, dv = arrays(B)
+    rep = np.repeat(np.arange(len(ix)), 1 + (np.arange(len(ix)) % 3 == 0))
+    cnt = np.bincount(np.searchsorted(ip, rep, side="right") - 1, minlength=B.shape[0])
+    ip2 = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    Bd = (ip2, ix[rep].copy(), dv[rep].copy())
+    want = oracle.sparse(arrays(A), Bd, 400)
+    a = ctx.csr_from_scipy(A); b = ctx.csr_from_arrays(120, 400, *Bd)
+    try:
+        assert not b.is_canonical()
+        got = ctx.spgemm_host(a, b)
+    finally:
+        a.close(); b.close()
+    assert_csr_equal(got, want, values="tol", rtol=RTOL)
+
+
+@pytest.mark.parametrize("m,k,n,da,db", CASES)
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_dense_matches_oracle(ctx, oracle, m, k, n, da, db, symmetric):
+    if symmetric and m != n:
+        pytest.skip("symmetric needs a square result")
+    A, B = signed(rand_csr(m, k, da, 11), 1), signed(rand_csr(k, n, db, 12), 2)
+    want = oracle.dense(arrays(A), arrays(B), n, symmetric=symmetric)
+    a, b = ctx.csr_from_scipy(A), ctx.csr_from_scipy(B)
+    try:
+        got = ctx.dense_host(a, b, symmetric=symmetric)
+        got_u = ctx.dense_host(a, b, symmetric=symmetric, unordered=True)
+    finally:
+        a.close(); b.close()
+    assert np.array_equal(got.view(np.int64), want.view(np.int64)), f"max rel {rel_err(got, want):.3e}"
+    assert np.allclose(got_u, want, rtol=1e-9, atol=1e-13)
+
+
+def test_dense_unsorted_b(ctx, oracle):
+    A, B = rand_csr(90, 80, 0.1, 13), shuffle_rows(rand_csr(80, 300, 0.1, 14), 15)
+    want = oracle.dense(arrays(A), arrays(B), 300)
+    a, b = ctx.csr_from_scipy(A), ctx.csr_from_scipy(B)
+    try:
+        got = ctx.dense_host(a, b)
+    finally:
+        a.close(); b.close()
+    assert rel_err(got, want) <= RTOL
+
+
+@pytest.mark.parametrize("n,k,dh,dq", [(1, 1, 1.0, 1.0), (60, 90, 0.1, 0.1), (500, 500, 0.3, 0.3),
+                                       (300, 9000, 0.02, 0.004), (257, 5000, 0.05, 0.01)])
+@pytest.mark.parametrize("full", [0, 1])
+def test_triple_matches_oracle(ctx, oracle, n, k, dh, dq, full):
+    H = rand_csr(n, k, dh, 21)
+    S = rand_csr(k, k, dq / 2, 22)
+    Q = (S + S.T).tocsr()
+    want = oracle.triple(arrays(H), arrays(Q), k, full=full)
+    h, q = ctx.csr_from_scipy(H), ctx.csr_from_scipy(Q)
+    try:
+        got = ctx.triple_host(h, q, full=bool(full))
+    finally:
+        h.close(); q.close()
+    assert np.array_equal(got.view(np.int64), want.view(np.int64)), f"max rel {rel_err(got, want):.3e}"
+
+
+def test_triple_row_range(ctx, oracle):
+    H = rand_csr(200, 300, 0.05, 23); S = rand_csr(300, 300, 0.02, 24); Q = (S + S.T).tocsr()
+    want = oracle.triple(arrays(H), arrays(Q), 300, full=0)
+    h, q = ctx.csr_from_scipy(H), ctx.csr_from_scipy(Q)
+    try:
+        top = ctx.triple_host(h, q, row_begin=0, row_end=77)
+        bot = ctx.triple_host(h, q, row_begin=77, row_end=200)
+    finally:
+        h.close(); q.close()
+    assert np.array_equal(np.vstack([top, bot]), want)
+
+
+def test_row_shards_concatenate_to_single_result(ctx, oracle):
+    """contiguous row shards, concatenated in order, ARE the single-device CSR."""
+    A, B = rand_csr(400, 300, 0.05, 31), rand_csr(300, 400, 0.05, 32)
+    for symmetric in (False, True):
+        want = oracle.sparse(arrays(A), arrays(B), 400, symmetric=symmetric)
+        b = ctx.csr_from_scipy(B)
+        ptrs, idxs, vals, base = [np.zeros(1, np.int64)], [], [], 0
+        try:
+            for r0, r1 in ((0, 90), (90, 250), (250, 400)):
+                a = ctx.csr_from_scipy(A[r0:r1])
+                p, i, v = ctx.spgemm_host(a, b, symmetric=symmetric, row_offset=r0)
+                a.close()
+                ptrs.append(p[1:] + base); base += p[-1]; idxs.append(i); vals.append(v)
+        finally:
+            b.close()
+        got = (np.concatenate(ptrs), np.concatenate(idxs), np.concatenate(vals))
+        assert_csr_equal(got, want, values="bits")
+
+
+def test_malformed_operand_is_rejected(ctx):
+    from sparse_matrix_mult_amd.engine import SmmError
+    indptr = np.array([0, 2, 3], dtype=np.int32)
+    with pytest.raises(SmmError):
+        ctx.csr_from_arrays(2, 3, indptr, np.array([0, 7, 1], dtype=np.int32), np.ones(3))      # column out of range
+    with pytest.raises(SmmError):
+        ctx.csr_from_arrays(2, 3, np.array([0, 3, 2], dtype=np.int32), np.array([0, 1, 2], dtype=np.int32), np.ones(3))
+    A = ctx.csr_from_scipy(sp.identity(3, format="csr")); B = ctx.csr_from_scipy(sp.identity(4, format="csr"))
+    with pytest.raises(SmmError):
+        ctx.spgemm_host(A, B)
+    A.close(); B.close()
