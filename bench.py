@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the CSR x CSR -> CSR hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows 50000] [--cols 50000] [--density 0.01]
+
+Workload (BASELINE.json configs[1]): A (rows x cols) times B (cols x cols), both uniform
+random CSR of the given density with uniform[0,1) float64 values -- the distribution of
+scipy.sparse.random, generated on the device (inputs are resident in HBM before the timed
+region; nothing from the host is in it).  One step = one whole product: symbolic phase
+(row counts + first-touch column order), scan, numeric phase, result left in HBM.
+
+Multi-GPU (weak scaling): rank r owns the contiguous row block [r*rows, (r+1)*rows) of a
+global (N*rows x cols) A; B is replicated.  The exchange step is the all-gather of the
+shards' row counts that turns local row pointers into the global CSR row pointer
+(sparse_matrix_mult_amd/distributed.py); indices/values stay sharded (a full all-gatherv of
+N x 30 GB does not fit one GPU at this size -- DESIGN.md "Multi-GPU").
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- algorithmic bytes of one product / average duration of the dominant kernel
+                  (smm_numeric), measured with HIP events on the launch stream
+  cpu_baseline -- the CPU oracle (oracle/, a port of the reference's algorithm) timed on a
+                  bounded row sample of the same operands on this box's host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def gen_csr_device(torch, rows, cols, density, seed, device):
+    """Uniform random CSR on the device: every cell is kept with probability `density`
+    (row lengths are binomial, as scipy.sparse.random's are to within sampling noise),
+    indices sorted inside rows, values uniform[0,1) float64."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    chunk = max(1, min(rows, (64 << 20) // max(cols, 1)))
+    idx_parts, cnt_parts = [], []
+    for r0 in range(0, rows, chunk):
+        r1 = min(rows, r0 + chunk)
+        mask = torch.rand((r1 - r0, cols), generator=g, device=device) < density
+        nz = mask.nonzero(as_tuple=False)                 # row-major -> sorted inside rows
+        idx_parts.append(nz[:, 1].to(torch.int32))
+        cnt_parts.append(mask.sum(dim=1))
+        del mask, nz
+    indices = torch.cat(idx_parts)
+    counts = torch.cat(cnt_parts)
+    indptr = torch.zeros(rows + 1, dtype=torch.int64, device=device)
+    indptr[1:] = torch.cumsum(counts, 0)
+    assert int(indptr[-1]) < 2 ** 31
+    data = torch.rand(indices.numel(), generator=g, device=device, dtype=torch.float64)
+    return indptr.to(torch.int32), indices, data
+
+
+def cpu_baseline(torch, a, b, cols, target_s=12.0):
+    """Time the oracle (kind 'port': our C restatement of src/sparsework.cpp) on the first R
+    rows of A against all of B, single thread, on this box's host."""
+    from oracle import oracle
+    ap, ai, av = (t.cpu().numpy() for t in a)
+    bp, bi, bv = (t.cpu().numpy() for t in b)
+    rows = len(ap) - 1
+    probe = max(1, min(rows, 64))
+    t0 = time.perf_counter()
+    oracle.sparse_rows((ap, ai, av), (bp, bi, bv), cols, 0, probe)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    sample = int(max(probe, min(rows, probe * target_s / dt)))
+    t0 = time.perf_counter()
+    cnt, _, _ = oracle.sparse_rows((ap, ai, av), (bp, bi, bv), cols, 0, sample)
+    dt = time.perf_counter() - t0
+    return {"value": float(cnt.sum() / dt), "unit": "nnz/s", "cores": 1, "kind": "port",
+            "sample": f"first {sample} of {rows} rows of A x all of B, {int(cnt.sum())} output nnz in {dt:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rows", type=int, default=50000)
+    ap.add_argument("--cols", type=int, default=50000)
+    ap.add_argument("--density", type=float, default=0.01)
+    ap.add_argument("--unordered", action="store_true", help="SMM_UNORDERED numeric phase")
+    ap.add_argument("--lds-cols", type=int, default=0)
+    ap.add_argument("--waves", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from sparse_matrix_mult_amd.engine import Context
+    from sparse_matrix_mult_amd import distributed as smm_dist
+
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = Context(local, stream)
+    if args.lds_cols or args.waves:
+        ctx.tune(args.lds_cols, args.waves)
+
+    m, n, d = args.rows, args.cols, args.density
+    a_t = gen_csr_device(torch, m, n, d, 1 + 1000 * rank, device)      # rank's row block of A
+    b_t = gen_csr_device(torch, n, n, d, 2, device)                   # B, replicated
+    A = ctx.csr_from_torch(m, n, *a_t)
+    B = ctx.csr_from_torch(n, n, *b_t)
+    nnz_a, nnz_b = A.nnz, B.nnz
+
+    def step():
+        plan = ctx.spgemm_plan(A, B, unordered=args.unordered, row_offset=rank * m)
+        indptr = torch.empty(m + 1, dtype=torch.int64, device=device)
+        indices = torch.empty(plan.nnz, dtype=torch.int32, device=device)
+        data = torch.empty(plan.nnz, dtype=torch.float64, device=device)
+        plan.numeric_into(indptr.data_ptr(), indices.data_ptr(), data.data_ptr())
+        plan.close()
+        if world > 1:
+            indptr = smm_dist.global_indptr(indptr, dist)               # the exchange step
+        return indptr, indices, data
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+        del out
+    ctx.timing(True)
+    ctx.timing_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+        nnz_c = int(out[1].numel())
+        del out
+    fence()
+    elapsed = time.perf_counter() - t0
+    num_ms, num_n = ctx.kernel_time("smm_numeric")
+    sym_ms, sym_n = ctx.kernel_time("smm_symbolic")
+    ctx.timing(False)
+
+    t = torch.tensor([elapsed, float(nnz_c)], dtype=torch.float64, device=device)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, total_nnz = float(tmax[0]), float(t[1])
+    else:
+        total_nnz = float(nnz_c)
+
+    if rank == 0:
+        # compulsory one-touch bytes of one product
+        alg_bytes = (4 * (m + 1) + 12 * nnz_a) + (4 * (n + 1) + 12 * nnz_b) + (8 * (m + 1) + 12 * nnz_c)
+        num_avg_s = (num_ms / max(num_n, 1)) * 1e-3
+        achieved = alg_bytes / num_avg_s / 1e9 if num_avg_s > 0 else 0.0
+        line = {
+            "metric": "output nnz/sec, CSR x CSR -> CSR SpGEMM (first-touch order, float64)",
+            "value": total_nnz * args.steps / elapsed,
+            "unit": "nnz/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{m}x{n} x {n}x{n} uniform random CSR d={d} -> CSR, per GPU "
+                                   f"(BASELINE configs[1])",
+                       "nnz_a": nnz_a, "nnz_b": nnz_b, "nnz_c_per_gpu": nnz_c,
+                       "mode": "unordered" if args.unordered else "ordered (bit-exact values)",
+                       "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "smm_numeric", "kernel_ms": num_ms / max(num_n, 1),
+                         "algorithmic_bytes": alg_bytes,
+                         "symbolic_kernel_ms": sym_ms / max(sym_n, 1)},
+        }
+        if not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(torch, a_t, b_t, n)
+        print(json.dumps(line), flush=True)
+
+    A.close(); B.close(); ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
