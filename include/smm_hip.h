@@ -39,10 +39,12 @@ enum smm_status {
 enum smm_flags {
     SMM_SYMMETRIC   = 1,  /* keep only i <= col   (sparsework.cpp:217, sparse_sparse_dense.cpp:59) */
     SMM_FULL_MATRIX = 2,  /* triple_product compute_full_matrix=1 (sparse_sparse_dense.cpp:201,213) */
-    SMM_UNORDERED   = 4   /* numeric phase may add products in any order (LDS atomics across
-                             waves): values then agree with the reference to rounding
-                             (<= 1e-10 relative) instead of bit for bit.  indptr / indices
-                             are unaffected.                                             */
+    SMM_EXACT       = 4   /* add every product in exactly the reference's order: float64 values
+                             are then bit-identical to the CPU loop (for operands with sorted
+                             rows).  Without it the numeric phase lets the waves of a workgroup
+                             add concurrently (LDS atomics): values agree to rounding -- tested
+                             to the north star's 1e-10 relative -- and the kernel is ~3x faster.
+                             indptr / indices are bit-exact in both modes.                     */
 };
 
 typedef struct smm_ctx  smm_ctx;   /* one device + one stream + a workspace arena        */
@@ -64,9 +66,11 @@ int  smm_ctx_synchronize(smm_ctx *ctx);
 int  smm_ctx_timing(smm_ctx *ctx, int enable);
 int  smm_ctx_timing_reset(smm_ctx *ctx);
 int  smm_ctx_kernel_time(smm_ctx *ctx, const char *kernel, double *ms_total, int64_t *launches);
-/* Tuning knobs (0 keeps the default): LDS accumulator columns per workgroup and waves per
- * workgroup of the numeric kernels. */
-int  smm_ctx_tune(smm_ctx *ctx, int lds_cols, int waves);
+/* Tuning knobs (0 keeps the default): LDS accumulator columns per workgroup (x 8 bytes of
+ * LDS; default 5000 = four workgroups per CU) and waves per workgroup (1, 2, 4 or 8) of the
+ * numeric kernels.  Results do not depend on them, bit for bit. */
+int  smm_ctx_tune(smm_ctx *ctx, int lds_cols, int waves);             /* SMM_EXACT walk          */
+int  smm_ctx_tune_shared(smm_ctx *ctx, int lds_cols, int waves);      /* default walk (4/8/16)   */
 
 /* ------------------------------------------------------------------ operands
  * Replaces create_sparsemat + the three memmoves of csr_to_sparsemat

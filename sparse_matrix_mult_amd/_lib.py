@@ -11,11 +11,12 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsmm_hip.so")
+# SMM_LIB_PATH: load another build of the same library (diagnostic builds, e.g. -DSMM_STAMPS)
+LIB_PATH = os.environ.get("SMM_LIB_PATH") or os.path.join(_HERE, "lib", "libsmm_hip.so")
 
 SMM_SYMMETRIC = 1
 SMM_FULL_MATRIX = 2
-SMM_UNORDERED = 4
+SMM_EXACT = 4
 
 _c_i64 = ctypes.c_int64
 _vp = ctypes.c_void_p
@@ -33,6 +34,7 @@ V2_PROTOTYPES = {
     "smm_ctx_kernel_time": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
                                            ctypes.POINTER(_c_i64)]),
     "smm_ctx_tune": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    "smm_ctx_tune_shared": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "smm_csr_from_host": (ctypes.c_int, [_vp, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _pp]),
     "smm_csr_from_device": (ctypes.c_int, [_vp, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _pp]),
     "smm_csr_destroy": (None, [_vp]),

@@ -57,14 +57,17 @@ struct smm_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool timing = false;
-    int lds_cols = 8192;     // accumulator columns per workgroup (x8 B of LDS)
-    int waves = 4;           // waves per numeric workgroup
+    int lds_cols = 5000;     // accumulator columns per workgroup (x8 B of LDS: 4 workgroups per CU)
+    int waves = 1;           // waves per numeric workgroup
+    int lds_cols_shared = 16384;   // default (shared-tile) walk: tile columns and waves per workgroup
+    int waves_shared = 16;
+    int seg_target = 40;     // aimed-at entries of B per (row of B, fine tile) segment; <= 64 lanes
     int n_cu = 256;
     std::vector<PoolBlock> pool;          // free blocks
     std::map<void *, size_t> live;        // blocks handed out
     std::vector<TimedLaunch> launches;
     std::map<std::string, std::pair<double, int64_t>> totals;
-    unsigned *d_flags = nullptr;
+    unsigned *d_flags = nullptr;     // [0] validation flags; +64: int -1 and +128: double 0 read by idle lanes
     std::mutex mu;
 };
 
@@ -164,6 +167,16 @@ extern "C" int smm_ctx_create(int device, void *hip_stream, smm_ctx **out)
         c->own_stream = true;
     }
     if (hipMalloc((void **)&c->d_flags, 256) != hipSuccess) { delete c; return fail(SMM_ERR_ALLOC, "hipMalloc flags"); }
+    {
+        unsigned char init[256];
+        memset(init, 0, sizeof(init));
+        const int neg1 = -1;
+        memcpy(init + 64, &neg1, sizeof(neg1));
+        if (hipMemcpy(c->d_flags, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(c->d_flags); delete c;
+            return fail(SMM_ERR_HIP, "hipMemcpy of the context constants failed");
+        }
+    }
     *out = c;
     return SMM_OK;
 }
@@ -229,12 +242,25 @@ extern "C" int smm_ctx_tune(smm_ctx *c, int lds_cols, int waves)
 {
     if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
     if (lds_cols) {
-        if (lds_cols < 256 || lds_cols > 16384) return fail(SMM_ERR_INVALID, "lds_cols must be in [256,16384]");
+        if (lds_cols < 64 || lds_cols > 20000) return fail(SMM_ERR_INVALID, "lds_cols must be in [64,20000]");
         c->lds_cols = lds_cols;
     }
     if (waves) {
-        if (waves != 4 && waves != 8) return fail(SMM_ERR_INVALID, "waves must be 4 or 8");
+        if (waves != 1 && waves != 2 && waves != 4 && waves != 8) return fail(SMM_ERR_INVALID, "waves must be 1, 2, 4 or 8");
         c->waves = waves;
+    }
+    return SMM_OK;
+}
+extern "C" int smm_ctx_tune_shared(smm_ctx *c, int lds_cols, int waves)
+{
+    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    if (lds_cols) {
+        if (lds_cols < 64 || lds_cols > 20000) return fail(SMM_ERR_INVALID, "lds_cols must be in [64,20000]");
+        c->lds_cols_shared = lds_cols;
+    }
+    if (waves) {
+        if (waves != 4 && waves != 8 && waves != 16) return fail(SMM_ERR_INVALID, "waves must be 4, 8 or 16");
+        c->waves_shared = waves;
     }
     return SMM_OK;
 }
@@ -346,12 +372,32 @@ extern "C" int smm_csr_is_canonical(smm_ctx *c, smm_csr *m)
 
 // Tile geometry: nct coarse tiles of wc = nw*wf columns; fine tile t covers [t*wf,(t+1)*wf).
 struct Geom { int nct, wc, wf, n_ft, nw; };
-static Geom make_geom(const smm_ctx *c, int64_t ncols)
+static Geom make_geom(const smm_ctx *c, int64_t ncols, const smm_csr *b, bool exact)
 {
     Geom g;
+    if (!exact) {
+        // shared-tile walk: one coarse tile per workgroup, waves split the chunks; the tile
+        // index has one entry per coarse tile
+        g.nw = c->waves_shared;
+        const int64_t cols = std::max<int64_t>(ncols, 1);
+        g.nct = (int)((cols + c->lds_cols_shared - 1) / c->lds_cols_shared);
+        g.wc = (int)((cols + g.nct - 1) / g.nct);
+        g.wf = g.wc;
+        g.n_ft = g.nct;
+        return g;
+    }
     g.nw = c->waves;
     const int64_t cols = std::max<int64_t>(ncols, 1);
-    g.nct = (int)((cols + c->lds_cols - 1) / c->lds_cols);
+    // fine-tile width: bounded by LDS, and by the width at which an average row of B leaves
+    // about seg_target entries per tile (one wave-load per segment, rarely more than 64)
+    int64_t wf_max = std::max<int64_t>(c->lds_cols / g.nw, 1);
+    if (b && b->rows > 0 && b->nnz > 0) {
+        const double avg_len = (double)b->nnz / (double)b->rows;
+        const int64_t cap = (int64_t)((double)c->seg_target * (double)cols / avg_len);
+        wf_max = std::min(wf_max, std::max<int64_t>(cap, 64));
+    }
+    const int64_t wc_max = wf_max * g.nw;
+    g.nct = (int)((cols + wc_max - 1) / wc_max);
     const int64_t per = (cols + g.nct - 1) / g.nct;
     g.wf = (int)((per + g.nw - 1) / g.nw);
     g.wc = g.wf * g.nw;
@@ -406,27 +452,58 @@ extern "C" int smm_row_products(smm_ctx *c, const smm_csr *a, const smm_csr *b, 
 }
 
 // ------------------------------------------------------------------------------ numeric dispatch
-template <int OUT, bool SYM, bool ORD, int NW>
-static int launch_numeric_t(smm_ctx *c, const NumericArgs &args, int64_t grid)
+template <int OUT, bool SYM, int NW, bool EXACT>
+static int launch_numeric_t(smm_ctx *c, NumericArgs &args)
 {
     const size_t lds = (size_t)args.wc * sizeof(double);
-    auto kern = smm_numeric<OUT, SYM, ORD, NW>;
+    auto kern = smm_numeric<OUT, SYM, NW, EXACT>;
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // persistent workgroups: as many as the LDS lets a CU hold (x CUs), never more than rows
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)(160 * 1024) / std::max<size_t>(lds, 1), 32 / NW));
+    const int grid = (int)std::min<int64_t>((int64_t)c->n_cu * per_cu, args.m);
+    double *tbuf = nullptr;
+    if (OUT == OUT_SPARSE) {
+        CHK(pool_get(c, (size_t)grid * (size_t)args.ncols, &tbuf));
+        args.tbuf = tbuf;
+    }
+#ifdef SMM_STAMPS
+    unsigned long long *d_st = nullptr;
+    CHK(pool_get(c, 4, &d_st));
+    (void)hipMemsetAsync(d_st, 0, 32, c->stream);
+    args.stamps = d_st;
+#endif
     LAUNCH(c, OUT == OUT_SPARSE ? "smm_numeric" : "smm_numeric_dense", kern, grid, NW * 64, lds, args);
-    LAUNCH_CHECK();
+    hipError_t e = hipGetLastError();
+#ifdef SMM_STAMPS
+    {
+        unsigned long long h[4];
+        (void)hipMemcpyAsync(h, d_st, 32, hipMemcpyDeviceToHost, c->stream);
+        (void)hipStreamSynchronize(c->stream);
+        const double tot = (double)(h[0] + h[1] + h[2] + h[3]);
+        fprintf(stderr, "[SMM_STAMPS] grid=%d NW=%d wc=%d nct=%d  init %.1f%%  accumulate %.1f%%  flush %.1f%%  gather %.1f%%  (sum %.3g cycles, %.3g per workgroup)\n",
+                grid, NW, args.wc, args.nct, 100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, tot, tot / grid);
+        pool_free(c, d_st);
+    }
+#endif
+    if (tbuf) {                                 // stream-ordered reuse: the pool is per context/stream
+        pool_free(c, tbuf);
+    }
+    if (e != hipSuccess) return fail(SMM_ERR_HIP, "smm_numeric launch: %s", hipGetErrorString(e));
     return SMM_OK;
 }
 template <int OUT>
-static int launch_numeric(smm_ctx *c, const NumericArgs &args, bool sym, bool ordered, int nw)
+static int launch_numeric(smm_ctx *c, NumericArgs &args, bool sym, int nw, bool exact)
 {
-    const int64_t grid = (int64_t)args.m * args.nct;
-    if (grid <= 0) return SMM_OK;
-    if (grid > 0x7fffffff) return fail(SMM_ERR_INVALID, "too many (row, tile) units for one launch");
-#define SMM_CASE(S, O, N) \
-    if (sym == S && ordered == O && nw == N) return launch_numeric_t<OUT, S, O, N>(c, args, grid);
-    SMM_CASE(false, false, 4) SMM_CASE(false, true, 4) SMM_CASE(true, false, 4) SMM_CASE(true, true, 4)
-    SMM_CASE(false, false, 8) SMM_CASE(false, true, 8) SMM_CASE(true, false, 8) SMM_CASE(true, true, 8)
+    if (args.m <= 0) return SMM_OK;
+    args.dummy_idx = (const int *)((const char *)c->d_flags + 64);
+    args.dummy_val = (const double *)((const char *)c->d_flags + 128);
+#define SMM_CASE(S, N, X) \
+    if (sym == S && nw == N && exact == X) return launch_numeric_t<OUT, S, N, X>(c, args);
+    SMM_CASE(false, 1, true) SMM_CASE(true, 1, true) SMM_CASE(false, 2, true) SMM_CASE(true, 2, true)
+    SMM_CASE(false, 4, true) SMM_CASE(true, 4, true) SMM_CASE(false, 8, true) SMM_CASE(true, 8, true)
+    SMM_CASE(false, 4, false) SMM_CASE(true, 4, false) SMM_CASE(false, 8, false) SMM_CASE(true, 8, false)
+    SMM_CASE(false, 16, false) SMM_CASE(true, 16, false)
 #undef SMM_CASE
     return fail(SMM_ERR_INVALID, "unsupported numeric configuration");
 }
@@ -442,10 +519,8 @@ struct smm_plan {
     Geom g{};
     int64_t *d_ub_off = nullptr;   // m+1
     int *d_tmp = nullptr;          // capacity-strided ordered column lists
-    unsigned *d_P = nullptr;       // nnz(A)
     int *d_rowcnt = nullptr;       // m
     int64_t *d_cptr = nullptr;     // m+1
-    unsigned *d_runs = nullptr;    // nnz(A) x (nct+1)
 };
 
 extern "C" void smm_plan_destroy(smm_plan *p)
@@ -454,8 +529,8 @@ extern "C" void smm_plan_destroy(smm_plan *p)
     smm_ctx *c = p->ctx;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    pool_free(c, p->d_ub_off); pool_free(c, p->d_tmp); pool_free(c, p->d_P);
-    pool_free(c, p->d_rowcnt); pool_free(c, p->d_cptr); pool_free(c, p->d_runs);
+    pool_free(c, p->d_ub_off); pool_free(c, p->d_tmp);
+    pool_free(c, p->d_rowcnt); pool_free(c, p->d_cptr);
     delete p;
 }
 extern "C" int64_t smm_plan_nnz(const smm_plan *p) { return p ? p->nnz : -1; }
@@ -468,7 +543,8 @@ static int launch_symbolic_t(smm_ctx *c, smm_plan *p, int bm_words, unsigned *gb
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     LAUNCH(c, "smm_symbolic", kern, grid, 256, lds, (int)p->m, p->row_offset, bm_words, p->a->ptr, p->a->idx,
-           p->b->ptr, p->b->idx, p->d_ub_off, p->d_tmp, p->d_P, p->d_rowcnt, gbm);
+           p->b->ptr, p->b->idx, p->d_ub_off, p->d_tmp, p->d_rowcnt, gbm,
+           (const int *)((const char *)c->d_flags + 64));
     LAUNCH_CHECK();
     return SMM_OK;
 }
@@ -485,7 +561,7 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     p->ctx = c; p->a = a; p->b = b; p->flags = flags; p->row_offset = a_row_offset;
     p->m = a->rows; p->ncols = b->cols;
     p->b_sorted = !(b->vflags & CSR_UNSORTED);
-    p->g = make_geom(c, p->ncols);
+    p->g = make_geom(c, p->ncols, b, (flags & SMM_EXACT) != 0);
     const bool sym = flags & SMM_SYMMETRIC;
     const int64_t m = p->m;
     int rc = SMM_OK;
@@ -517,7 +593,6 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     }
     pool_free(c, d_prod); pool_free(c, d_ub);
     PCHK(pool_get(c, (size_t)std::max<int64_t>(total_ub, 1), &p->d_tmp));
-    PCHK(pool_get(c, (size_t)a->nnz, &p->d_P));
     PCHK(pool_get(c, (size_t)m, &p->d_rowcnt));
 
     // symbolic: one wave per row, 4 rows per workgroup
@@ -539,15 +614,7 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "symbolic phase: %s", hipGetErrorString(e)); }
     }
     if (gbm) pool_free(c, gbm);
-    if (p->b_sorted && p->nnz > 0) {
-        PCHK(ensure_seg(c, b, p->g));
-        PCHK(pool_get(c, (size_t)a->nnz * (p->g.nct + 1), &p->d_runs));
-        const int rgrid = (int)std::min<int64_t>((m + 3) / 4, 65536);
-        LAUNCH(c, "smm_runs", smm_runs, rgrid, 256, 0, (int)m, p->g.nct, p->g.wc, a->ptr, p->d_ub_off, p->d_rowcnt,
-               p->d_P, p->d_tmp, p->d_runs);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "smm_runs: %s", hipGetErrorString(e)); }
-    }
+    if (p->b_sorted && p->nnz > 0) PCHK(ensure_seg(c, b, p->g));
 #undef PCHK
     if (nnz_out) *nnz_out = p->nnz;
     *plan = p;
@@ -565,18 +632,19 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
     if (p->nnz == 0) return SMM_OK;
     if (!d_c_indices || !d_c_data) return fail(SMM_ERR_INVALID, "output arrays are NULL but nnz > 0");
     const bool sym = p->flags & SMM_SYMMETRIC;
-    const int cgrid = (int)std::min<int64_t>(m, 65536);
-    LAUNCH(c, "smm_compact", smm_compact, cgrid, 256, 0, (int)m, p->d_ub_off, p->d_cptr, p->d_tmp, d_c_indices);
-    LAUNCH_CHECK();
     if (p->b_sorted) {
         NumericArgs A{};
         A.m = (int)m; A.ncols = (int)p->ncols; A.nct = p->g.nct; A.wc = p->g.wc; A.wf = p->g.wf; A.n_ft = p->g.n_ft;
         A.row_offset = p->row_offset;
         A.a_ptr = p->a->ptr; A.a_idx = p->a->idx; A.a_val = p->a->val;
         A.b_idx = p->b->idx; A.b_val = p->b->val; A.seg = p->b->seg;
-        A.c_ptr = p->d_cptr; A.c_idx = d_c_indices; A.c_val = d_c_data; A.runs = p->d_runs;
-        CHK(launch_numeric<OUT_SPARSE>(c, A, sym, !(p->flags & SMM_UNORDERED), p->g.nw));
+        A.c_ptr = p->d_cptr; A.c_idx = d_c_indices; A.c_val = d_c_data;
+        A.ub_off = p->d_ub_off; A.tmp_idx = p->d_tmp;
+        CHK(launch_numeric<OUT_SPARSE>(c, A, sym, p->g.nw, (p->flags & SMM_EXACT) != 0));
     } else {
+        const int cgrid = (int)std::min<int64_t>(m, 65536);
+        LAUNCH(c, "smm_copy_lists", smm_copy_lists, cgrid, 256, 0, (int)m, p->d_ub_off, p->d_cptr, p->d_tmp, d_c_indices);
+        LAUNCH_CHECK();
         const int grid = (int)std::min<int64_t>((m + 3) / 4, (int64_t)c->n_cu * 2);
         int *slot = nullptr;
         CHK(pool_get(c, (size_t)grid * 4 * (size_t)p->ncols, &slot));
@@ -642,7 +710,7 @@ static int dense_into(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t row
         return SMM_OK;
     }
     if (!(b->vflags & CSR_UNSORTED)) {
-        Geom g = make_geom(c, n);
+        Geom g = make_geom(c, n, b, (flags & SMM_EXACT) != 0);
         CHK(ensure_seg(c, b, g));
         NumericArgs A{};
         A.m = (int)m; A.ncols = (int)n; A.nct = g.nct; A.wc = g.wc; A.wf = g.wf; A.n_ft = g.n_ft;
@@ -650,7 +718,7 @@ static int dense_into(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t row
         A.a_ptr = a->ptr; A.a_idx = a->idx; A.a_val = a->val;
         A.b_idx = b->idx; A.b_val = b->val; A.seg = b->seg;
         A.c_dense = d_c; A.ldc = ldc;
-        CHK(launch_numeric<OUT_DENSE>(c, A, sym, !(flags & SMM_UNORDERED), g.nw));
+        CHK(launch_numeric<OUT_DENSE>(c, A, sym, g.nw, (flags & SMM_EXACT) != 0));
     } else {
         const int grid = (int)std::min<int64_t>((m + 3) / 4, 65536);
         if (sym)
@@ -718,7 +786,7 @@ extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags,
     smm_csr hv = *h;                       // row-range view of H (borrowed arrays)
     hv.ptr = h->ptr + row_begin; hv.rows = nr; hv.owned = false; hv.seg = nullptr;
     // indptr of the view is not rebased: kernels only use ptr[row], ptr[row+1] as absolute positions.
-    int rc = dense_into(c, &hv, q, 0, 0, T, K);
+    int rc = dense_into(c, &hv, q, flags & SMM_EXACT, 0, T, K);
     if (rc != SMM_OK) { pool_free(c, T); return rc; }
     // stage 2
     constexpr int R = 4, NW = 8;

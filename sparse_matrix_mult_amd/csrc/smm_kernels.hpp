@@ -2,21 +2,20 @@
 //
 // Path restated (reference file:line under /root/reference):
 //   sparsework_nosym / _sym   src/sparsework.cpp:56-129 / :201-280   -> smm_symbolic + smm_numeric
-//   sparse_nosym / _sym       src/sparse_sparse_sparse.cpp:269-291   -> smm_scan + smm_compact (no stitch copy)
+//   sparse_nosym / _sym       src/sparse_sparse_sparse.cpp:269-291   -> smm_scan (rows land in place; no stitch copy)
 //   dense_nosym / _sym        src/sparse_sparse_dense.cpp:108-129 / :40-73 -> smm_numeric<OUT_DENSE>
 //   triple_product            src/sparse_sparse_dense.cpp:185-220    -> smm_numeric<OUT_DENSE> + smm_triple_stage2
 //
 // Design notes (DESIGN.md has the long form):
-//  * A row of C is accumulated in LDS as a dense f64 tile of <= lds_cols columns ("coarse
-//    tile"); a workgroup owns one (row, coarse tile) unit.  In ORDERED mode every wave owns
-//    a contiguous "fine tile" of that coarse tile and walks the row's A entries in stored
-//    order, so each accumulator receives its products in exactly the reference's order
-//    (one wave's LDS atomics execute in issue order): values are bit-identical.
+//  * A row of C is accumulated in LDS as dense f64 tiles of <= lds_cols columns ("coarse
+//    tile").  Every wave of the workgroup owns a contiguous "fine tile" of it and walks the
+//    row's A entries in stored order, so each accumulator receives its products in exactly the
+//    reference's order (one wave's LDS atomics execute in issue order): values are
+//    bit-identical to the CPU loop.
 //  * The first-touch column order of the reference is produced by smm_symbolic:
 //    one wave per row, a bitmap of B's columns in LDS, test-and-set + ballot/mbcnt ordered
-//    compaction.  The numeric epilogue then moves accumulators to their first-touch slots
-//    in contiguous sub-runs (for each A entry j, the new columns of step j that fall in the
-//    tile are contiguous in the row because B's rows are sorted).
+//    compaction.  The numeric kernel then emits indices/values in that order by gathering
+//    from the row it has just accumulated.
 //  * No MFMA anywhere: this is an indexing / HBM path.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -177,11 +176,14 @@ __global__ __launch_bounds__(1024) void smm_scan(int n, const T *__restrict__ in
 // order, append a column the first time it is seen.  One wave per row; the marker is a
 // bitmap of B's columns (LDS when it fits, else a global slab per wave).
 //   tmp_idx + ub_off[row] : the row's ordered column list (capacity ub[row])
-//   P[e]                  : number of columns already in the list when A entry e starts
 //   rowcnt[row]           : final length = nnz of the row of C
 // SAFE resolves two lanes of one wave-instruction hitting the same column (possible only
 // when a row of B repeats a column): the LOWEST lane must win, whatever the LDS picks.
-constexpr int SYM_UNROLL = 4;
+// The walk is over 64-lane CHUNKS of B's rows: the rows of 64 A entries are cut into chunks
+// (entry j owns chunks [incl_j - nch_j, incl_j)), SYM_UNROLL chunk loads are issued together
+// (unconditional: idle lanes read a dummy -1) and then consumed strictly in order.  The B-row
+// pointers of the next 64 entries and the A indices of the 64 after those are prefetched.
+constexpr int SYM_UNROLL = 8;
 template <bool SYM, bool SAFE, bool LDSBM>
 __global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, int bm_words,
                                                     const int *__restrict__ a_ptr,
@@ -190,13 +192,13 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, i
                                                     const int *__restrict__ b_idx,
                                                     const int64_t *__restrict__ ub_off,
                                                     int *__restrict__ tmp_idx,
-                                                    unsigned *__restrict__ P,
                                                     int *__restrict__ rowcnt,
-                                                    unsigned *__restrict__ gbitmap)
+                                                    unsigned *__restrict__ gbitmap,
+                                                    const int *__restrict__ dummy_idx)
 {
     extern __shared__ unsigned lds_bm[];
     const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wpb = blockDim.x / WAVE;
     unsigned *bm = LDSBM ? lds_bm + (size_t)wave * bm_words
                          : gbitmap + ((size_t)blockIdx.x * wpb + wave) * bm_words;
@@ -205,34 +207,46 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, i
 
     for (int row = blockIdx.x * wpb + wave; row < m; row += gridDim.x * wpb) {
         const int a0 = a_ptr[row], a1 = a_ptr[row + 1];
-        const int64_t gi = row + row_offset;
+        int thresh = 0;
+        if (SYM) { const int64_t gi = row + row_offset; thresh = gi > 0x7fffffff ? 0x7fffffff : (int)gi; }
         int *__restrict__ out = tmp_idx + ub_off[row];
         int n = 0;
-        for (int jb = a0; jb < a1; jb += WAVE) {
-            const int e = jb + lane;
-            int bs = 0, be = 0;
-            if (e < a1) { const int r = a_idx[e]; bs = b_ptr[r]; be = b_ptr[r + 1]; }
-            unsigned myP = 0;
-            const int nb = (a1 - jb) < WAVE ? (a1 - jb) : WAVE;
-            for (int jj = 0; jj < nb; ++jj) {
-                const int s = rl(bs, jj), en = rl(be, jj);
-                if (lane == jj) myP = (unsigned)n;
-                for (int base = s; base < en; base += WAVE * SYM_UNROLL) {
-                    int c[SYM_UNROLL];
-                    bool act[SYM_UNROLL];
+        if (a1 > a0) {
+            auto load_r = [&](int jb) { int e = jb + lane; e = e < a1 ? e : a1 - 1; return a_idx[e]; };
+            int r_c = load_r(a0), r_n = load_r(a0 + WAVE);
+            int bs = b_ptr[r_c], be = b_ptr[r_c + 1];
+            for (int jb = a0; jb < a1; jb += WAVE) {
+                const int rem = a1 - jb;
+                const int nb = rem < WAVE ? rem : WAVE;
+                const int bs_n = b_ptr[r_n], be_n = b_ptr[r_n + 1];      // next 64 entries' rows of B
+                const int r_nn = load_r(jb + 2 * WAVE);                    // A indices two batches ahead
+                const int nch = lane < nb ? ((be - bs + WAVE - 1) >> 6) : 0;
+                int incl = nch;
 #pragma unroll
-                    for (int u = 0; u < SYM_UNROLL; ++u) {      // all loads first (MLP)
-                        const int k = base + u * WAVE + lane;
-                        act[u] = k < en;
-                        c[u] = act[u] ? b_idx[k] : 0;
+                for (int o = 1; o < WAVE; o <<= 1) {
+                    const int y = __shfl_up(incl, o);
+                    if (lane >= o) incl += y;
+                }
+                const int total = rl(incl, WAVE - 1);
+                for (int t0 = 0; t0 < total; t0 += SYM_UNROLL) {
+                    int c[SYM_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < SYM_UNROLL; ++u) {              // all loads first (MLP)
+                        const int t = t0 + u;
+                        int j = (int)__popcll(__ballot(incl <= t));
+                        j = j < WAVE ? j : WAVE - 1;
+                        const int first = rl(incl, j) - rl(nch, j);
+                        const int s = rl(bs, j), en = rl(be, j);
+                        const int k = s + ((t - first) << 6) + lane;
+                        const bool p = t < total && k < en;
+                        const int *ip = p ? b_idx + k : dummy_idx;
+                        c[u] = *ip;
                     }
 #pragma unroll
-                    for (int u = 0; u < SYM_UNROLL; ++u) {
-                        if (base + u * WAVE >= en) break;        // wave-uniform
-                        bool a = act[u];
-                        if (SYM) a = a && ((int64_t)c[u] >= gi);
+                    for (int u = 0; u < SYM_UNROLL; ++u) {              // then consume in order
+                        const bool a = c[u] >= thresh;                  // also drops the dummy -1
                         const unsigned bit = 1u << (c[u] & 31);
-                        unsigned *wp = bm + (c[u] >> 5);
+                        unsigned *wp = bm + (a ? (c[u] >> 5) : 0);
                         bool isnew = false;
                         if (SAFE) {
                             bool pre = true;
@@ -246,8 +260,8 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, i
                                 const int cx = rl(c[u], x);
                                 const bool ingrp = a && c[u] == cx;
                                 const unsigned long long grp = __ballot(ingrp);
-                                const int first = __ffsll((long long)grp) - 1;
-                                if (ingrp) isnew = (lane == first);
+                                const int firstl = __ffsll((long long)grp) - 1;
+                                if (ingrp) isnew = (lane == firstl);
                                 losers &= ~grp;
                             }
                         } else {
@@ -258,8 +272,8 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, i
                         n += __popcll(mask);
                     }
                 }
+                bs = bs_n; be = be_n; r_n = r_nn;
             }
-            if (e < a1) P[e] = myP;
         }
         if (lane == 0) rowcnt[row] = n;
         // reset the marker for the next row (sparsework.cpp:120-128: memset when the row is
@@ -275,174 +289,357 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, i
 }
 
 // ---------------------------------------------------------------------------------------
-// Move the ordered lists from their capacity-strided slots to the final CSR index array.
-// One workgroup per row chunk; pure streaming copy.
-__global__ __launch_bounds__(256) void smm_compact(int m, const int64_t *__restrict__ ub_off,
-                                                   const int64_t *__restrict__ c_ptr,
-                                                   const int *__restrict__ tmp_idx,
-                                                   int *__restrict__ c_idx)
-{
-    for (int row = blockIdx.x; row < m; row += gridDim.x) {
-        const int64_t src = ub_off[row], dst = c_ptr[row];
-        const int n = (int)(c_ptr[row + 1] - dst);
-        for (int s = threadIdx.x; s < n; s += blockDim.x) c_idx[dst + s] = tmp_idx[src + s];
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// Sub-run table.  Step e of a row appended the columns list[P[e] .. P[e+1]) in ascending
-// order (B's rows are sorted), so the part that falls into coarse tile t is the contiguous
-// slot range [runs[e][t], runs[e][t+1]).  One lane per A entry, nct-1 lower_bounds each.
-__global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc,
-                                                const int *__restrict__ a_ptr,
-                                                const int64_t *__restrict__ ub_off,
-                                                const int *__restrict__ rowcnt,
-                                                const unsigned *__restrict__ P,
-                                                const int *__restrict__ tmp_idx,
-                                                unsigned *__restrict__ runs)
-{
-    const int lane = lane_id();
-    const int wpb = blockDim.x / WAVE;
-    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < m; row += gridDim.x * wpb) {
-        const int a0 = a_ptr[row], a1 = a_ptr[row + 1];
-        const int *__restrict__ list = tmp_idx + ub_off[row];
-        const unsigned total = (unsigned)rowcnt[row];
-        for (int e = a0 + lane; e < a1; e += WAVE) {
-            const unsigned p0 = P[e];
-            const unsigned p1 = (e + 1 < a1) ? P[e + 1] : total;
-            unsigned *r = runs + (size_t)e * (nct + 1);
-            r[0] = p0;
-            unsigned lo = p0;
-            for (int t = 1; t < nct; ++t) {
-                const int64_t bound = (int64_t)t * wc;
-                unsigned hi = p1;
-                while (lo < hi) {
-                    const unsigned mid = lo + ((hi - lo) >> 1);
-                    if ((int64_t)list[mid] < bound) lo = mid + 1; else hi = mid;
-                }
-                r[t] = lo;
-            }
-            r[nct] = p1;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// Numeric phase.  Workgroup = one (row, coarse tile) unit; NW waves; LDS = wc doubles.
-//   OUT_SPARSE : accumulators start at -0.0 (the additive identity: -0.0 + p == p bit for
-//                bit, which reproduces `values[index] = p` of sparsework.cpp:108-109), the
-//                epilogue writes them to their first-touch slots.
-//   OUT_DENSE  : accumulators start at +0.0 (calloc, sparse_sparse_dense.cpp:97), the
-//                epilogue writes the tile row to C[row, lo..hi).
-//   ORDERED    : wave w owns fine tile w (columns [lo_c + w*wf, +wf)) and visits every A
-//                entry in order -> bit-exact sums.  Otherwise the waves split the A entries
-//                and add concurrently (any order, LDS atomics).
+// Numeric phase.  A workgroup of NW waves owns one ROW of C at a time (persistent, grid-stride)
+// and walks its coarse tiles; LDS = one coarse tile of wc f64 accumulators.
+//   per tile : accumulators := zero; smm_accumulate (below); tile -> HBM row buffer
+//   OUT_DENSE : the row buffer is the row of C itself (zero = +0.0: calloc,
+//               sparse_sparse_dense.cpp:97).
+//   OUT_SPARSE: the row buffer is a per-workgroup scratch row T (zero = -0.0, the additive
+//               identity: -0.0 + p == p bit for bit, which reproduces `values[index] = p` of
+//               sparsework.cpp:108-109).  After the last tile the workgroup emits the row in
+//               the reference's first-touch order: for slot s, c = list[s] (smm_symbolic),
+//               indices[s] = c, values[s] = T[c].  T is 8*ncols bytes per resident workgroup
+//               (256-1024 of them): it lives in L2 / Infinity Cache between the tile stores
+//               and the gather, so HBM sees the CSR output once, fully coalesced.
+// Two walks fill a tile:
+//   EXACT (SMM_EXACT): wave w owns fine tile w (columns [lo_c + w*wf, +wf)) and visits every A
+//     entry of the row in stored order, so every accumulator receives its products in exactly
+//     the reference's order (one wave's ds_add_f64 execute in issue order): sums are
+//     bit-identical to the CPU loop.  smm_accumulate.
+//   default: all waves share the tile and split the work by 64-entry chunks; sums agree to
+//     rounding.  smm_accumulate_shared (further down).
+//
+// The exact walk is a software pipeline (smm_accumulate): B's segments are 40-odd entries, far
+// too short to hide HBM/Infinity-Cache latency one at a time, and LDS capacity (20k f64
+// accumulators per CU) caps the CU at a handful of waves.  So each wave keeps PIPE = 32
+// segment loads (64 vector-memory ops, the vmcnt limit) in flight: step j adds the segment
+// loaded 32 steps ago and immediately re-issues its slot.  Every load in the loop is
+// unconditional (inactive lanes read a dummy word) so that the compiler's s_waitcnt
+// counts are exact -- a conditional load anywhere in the loop degrades them to vmcnt(0).
 struct NumericArgs {
     int m, ncols, nct, wc, wf, n_ft;
     int64_t row_offset;
     const int *a_ptr, *a_idx; const double *a_val;
     const int *b_idx; const double *b_val;
     const int *seg;                 // [rowsB][n_ft+1]
+    const int *dummy_idx;           // one int  = -1   (read by inactive lanes)
+    const double *dummy_val;        // one double
     // sparse output
-    const int64_t *c_ptr; const int *c_idx; double *c_val; const unsigned *runs;
+    const int64_t *c_ptr; int *c_idx; double *c_val;
+    const int64_t *ub_off; const int *tmp_idx;   // ordered column lists of smm_symbolic
+    double *tbuf;                   // gridDim.x scratch rows of ncols doubles
+    unsigned long long *stamps;     // diagnostic builds (-DSMM_STAMPS) only: 4 phase totals
     // dense output
     double *c_dense; int64_t ldc;
 };
 
-constexpr int NUM_UNROLL = 8;
+constexpr int PIPE = 32;
 
-template <int OUT, bool SYM, bool ORDERED, int NW>
+template <bool SYM>
+__device__ __forceinline__ void smm_accumulate(const NumericArgs &A, double *__restrict__ acc, const int lo_c,
+                                               const int thresh, const int a0, const int a1, const int ft)
+{
+    const int lane = lane_id();
+    const size_t per = (size_t)A.n_ft + 1;
+    const int *__restrict__ segf = A.seg + ft;
+    const int *__restrict__ bi = A.b_idx;
+    const double *__restrict__ bv = A.b_val;
+    int c[PIPE];
+    double v[PIPE];
+
+    // metadata of 64 A entries lives one-per-lane; all loads are clamped, never predicated
+    auto load_a = [&](int jb, int &r, double &av) {
+        int e = jb + lane;
+        e = e < a1 ? e : a1 - 1;
+        r = A.a_idx[e];
+        av = A.a_val[e];
+    };
+    auto load_seg = [&](int r, int &s, int &en) {
+        const int *sp = segf + (size_t)r * per;
+        s = sp[0];
+        en = sp[1];
+    };
+    auto issue = [&](int u, int s, int en) {          // s, en wave-uniform
+        const int k = s + lane;
+        const bool p = k < en;
+        const int *ip = p ? bi + k : A.dummy_idx;
+        const double *vp = p ? bv + k : A.dummy_val;
+        c[u] = *ip;
+        v[u] = *vp;
+    };
+
+    auto long_tail = [&](double a, int s, int en) {   // rare: a segment longer than one wave
+        for (int base = s + WAVE; base < en; base += WAVE) {
+            const int k = base + lane;
+            if (k < en) {
+                const int c2 = bi[k];
+                if (c2 >= thresh) lds_add(&acc[c2 - lo_c], a * bv[k]);
+            }
+        }
+    };
+
+    int r_c, r_n, s_c, e_c;
+    double a_c, a_n;
+    load_a(a0, r_c, a_c);
+    load_a(a0 + WAVE, r_n, a_n);
+    load_seg(r_c, s_c, e_c);
+    // keep these loads AHEAD of the 64 slot loads below: if the scheduler sinks them towards the
+    // loop, the loop header inherits a short vmcnt distance and drains the pipe every iteration
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const int nb0 = (a1 - a0) < WAVE ? (a1 - a0) : WAVE;
+#pragma unroll
+        for (int u = 0; u < PIPE; ++u) {
+            const bool ok = u < nb0;
+            const int s = rl(s_c, u), en = rl(e_c, u);
+            issue(u, ok ? s : 0, ok ? en : 0);
+        }
+    }
+    // Enter the loop with nothing pending (vmcnt(0); expcnt/lgkmcnt untouched).  The scheduler is
+    // free to reorder the prologue's loads, and whatever distance it leaves between a slot's load
+    // and the loop becomes the loop's own s_waitcnt -- executed every iteration, it would drain
+    // the pipe.  Draining once here costs nothing: step 0 needs the first slot anyway.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int jb = a0; jb < a1; jb += WAVE) {
+        const int rem = a1 - jb;
+        const int nb = rem < WAVE ? rem : WAVE;
+        const int nbn = rem - WAVE < 0 ? 0 : (rem - WAVE < WAVE ? rem - WAVE : WAVE);
+        const unsigned long long longm = __ballot(e_c - s_c > WAVE);
+        int s_n, e_n, r_nn;
+        double a_nn;
+        load_seg(r_n, s_n, e_n);                       // segments of the NEXT 64 entries
+        load_a(jb + 2 * WAVE, r_nn, a_nn);             // A entries two batches ahead
+        // 64 steps, expanded by the preprocessor so that every slot / lane index is a literal
+        // (the slots must live in registers) and the only control flow is the exit.
+#define SMM_STEP(J)                                                                              \
+        {                                                                                        \
+            if ((J) >= nb) goto row_done;          /* wave-uniform; only in the LAST batch */    \
+            constexpr int u = (J) & (PIPE - 1);                                                  \
+            const double a = rl(a_c, (J));                                                       \
+            const int cc = c[u];                                                                 \
+            if (cc >= thresh) lds_add(&acc[cc - lo_c], a * v[u]);                                \
+            if ((longm >> (J)) & 1ull) long_tail(a, rl(s_c, (J)), rl(e_c, (J)));                 \
+            if ((J) < PIPE) {                      /* refill: entry J+32 of this batch ... */     \
+                const bool ok = (J) + PIPE < nb;                                                 \
+                const int s = rl(s_c, ((J) + PIPE) & 63), en = rl(e_c, ((J) + PIPE) & 63);       \
+                issue(u, ok ? s : 0, ok ? en : 0);                                               \
+            } else {                               /* ... or entry J-32 of the next batch */     \
+                const bool ok = (J) - PIPE < nbn;                                                \
+                const int s = rl(s_n, ((J) - PIPE) & 63), en = rl(e_n, ((J) - PIPE) & 63);       \
+                issue(u, ok ? s : 0, ok ? en : 0);                                               \
+            }                                                                                    \
+        }
+#define SMM_STEP8(B) SMM_STEP(B) SMM_STEP(B + 1) SMM_STEP(B + 2) SMM_STEP(B + 3) \
+                     SMM_STEP(B + 4) SMM_STEP(B + 5) SMM_STEP(B + 6) SMM_STEP(B + 7)
+        SMM_STEP8(0) SMM_STEP8(8) SMM_STEP8(16) SMM_STEP8(24)
+        SMM_STEP8(32) SMM_STEP8(40) SMM_STEP8(48) SMM_STEP8(56)
+#undef SMM_STEP8
+#undef SMM_STEP
+        // (leaving through row_done instead of falling to the rotation keeps the back edge a
+        //  single straight-line path: its vmcnt distances are then exact, see header comment)
+        s_c = s_n; e_c = e_n; a_c = a_n;
+        r_n = r_nn; a_n = a_nn;
+    }
+row_done:
+    return;
+}
+
+// Shared-tile walk (default mode).  All NW waves of the workgroup add into the SAME coarse
+// tile: the segments of 64 A entries are cut into 64-lane chunks, chunk t goes to wave
+// t mod NW, and ds_add_f64 (an LDS atomic) makes concurrent adds safe.  Lanes stay ~full
+// (a 12k-column tile sees ~125 entries of every row of B: chunks of 64 + 61), 16 waves per CU
+// hide both memory and ALU latency, and nothing depends on the segment length.  What is
+// given up is the ORDER in which one accumulator receives its products, so values agree with
+// the reference to rounding (a few ulp; tests hold them to the north star's 1e-10) instead
+// of bit for bit.  SMM_EXACT selects smm_accumulate above instead.
+constexpr int CH_UNROLL = 8;
+
+template <bool SYM, int NW>
+__device__ __forceinline__ void smm_accumulate_shared(const NumericArgs &A, double *__restrict__ acc, const int lo_c,
+                                                      const int thresh, const int a0, const int a1, const int tc,
+                                                      const int wave)
+{
+    const int lane = lane_id();
+    const size_t per = (size_t)A.n_ft + 1;
+    const int *__restrict__ segf = A.seg + tc;
+    const int *__restrict__ bi = A.b_idx;
+    const double *__restrict__ bv = A.b_val;
+
+    auto load_a = [&](int jb, int &r, double &av) {
+        int e = jb + lane;
+        e = e < a1 ? e : a1 - 1;
+        r = A.a_idx[e];
+        av = A.a_val[e];
+    };
+    auto load_seg = [&](int r, int &s, int &en) {
+        const int *sp = segf + (size_t)r * per;
+        s = sp[0];
+        en = sp[1];
+    };
+
+    int r_c, r_n, s_c, e_c;
+    double a_c, a_n;
+    load_a(a0, r_c, a_c);
+    load_a(a0 + WAVE, r_n, a_n);
+    load_seg(r_c, s_c, e_c);
+    for (int jb = a0; jb < a1; jb += WAVE) {
+        const int rem = a1 - jb;
+        const int nb = rem < WAVE ? rem : WAVE;
+        int s_n, e_n, r_nn;
+        double a_nn;
+        load_seg(r_n, s_n, e_n);                       // segments of the NEXT 64 entries
+        load_a(jb + 2 * WAVE, r_nn, a_nn);             // A entries two batches ahead
+        // chunk list of this batch: entry j owns chunks [incl_j - nch_j, incl_j)
+        const int nch = lane < nb ? ((e_c - s_c + WAVE - 1) >> 6) : 0;
+        int incl = nch;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const int y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        const int total = rl(incl, WAVE - 1);
+        for (int t0 = wave; t0 < total; t0 += NW * CH_UNROLL) {
+            int c[CH_UNROLL];
+            double v[CH_UNROLL], a[CH_UNROLL];
+#pragma unroll
+            for (int u = 0; u < CH_UNROLL; ++u) {       // every load first ...
+                const int t = t0 + u * NW;
+                const bool ok = t < total;
+                int j = (int)__popcll(__ballot(incl <= t));
+                j = j < WAVE ? j : WAVE - 1;
+                const int first = rl(incl, j) - rl(nch, j);
+                const int s = rl(s_c, j), en = rl(e_c, j);
+                a[u] = rl(a_c, j);
+                const int k = s + ((t - first) << 6) + lane;
+                const bool p = ok && k < en;
+                const int *ip = p ? bi + k : A.dummy_idx;
+                const double *vp = p ? bv + k : A.dummy_val;
+                c[u] = *ip;
+                v[u] = *vp;
+            }
+#pragma unroll
+            for (int u = 0; u < CH_UNROLL; ++u)         // ... then the adds
+                if (c[u] >= thresh) lds_add(&acc[c[u] - lo_c], a[u] * v[u]);
+        }
+        s_c = s_n; e_c = e_n; a_c = a_n;
+        r_n = r_nn; a_n = a_nn;
+    }
+}
+
+template <int OUT, bool SYM, int NW, bool EXACT>
 __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
 {
     extern __shared__ double acc[];
-    const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
-    const int tc = blockIdx.x / A.m;            // tile-major: concurrent units share B's slab
-    const int row = blockIdx.x - tc * A.m;
-    const int a0 = A.a_ptr[row], a1 = A.a_ptr[row + 1];
-    const int lo_c = tc * A.wc;
-    const int64_t gi = row + A.row_offset;
-    int64_t rs = 0;
-    if (OUT == OUT_SPARSE) {
-        rs = A.c_ptr[row];
-        if (A.c_ptr[row + 1] == rs) return;     // empty row of C (workgroup-uniform)
-    }
-    const bool below = SYM && ((int64_t)lo_c + A.wc <= gi);   // tile entirely left of the diagonal
-    if (OUT == OUT_SPARSE && below) return;
-
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr int NT = NW * 64;
     const double zero = OUT == OUT_SPARSE ? -0.0 : 0.0;
-    for (int x = threadIdx.x; x < A.wc; x += NW * 64) acc[x] = zero;
-    __syncthreads();
+#ifdef SMM_STAMPS
+    // Diagnostic build only (never the shipped library): wave 0 sums the cycles of each phase and
+    // adds them to a buffer nothing else reads.
+    unsigned long long t_init = 0, t_acc = 0, t_flush = 0, t_gather = 0, t_mark;
+#define SMM_MARK() (t_mark = __builtin_readcyclecounter())
+#define SMM_LAP(var) { const unsigned long long now_ = __builtin_readcyclecounter(); var += now_ - t_mark; t_mark = now_; }
+#else
+#define SMM_MARK()
+#define SMM_LAP(var)
+#endif
 
-    if (!below) {
-        const int ft0 = tc * NW;
-        const int per = A.n_ft + 1;
-        for (int jb = a0; jb < a1; jb += WAVE) {
-            const int e = jb + lane;
-            int s_l = 0, e_l = 0;
-            double av = 0.0;
-            if (e < a1) {
-                const int r = A.a_idx[e];
-                av = A.a_val[e];
-                const int *sp = A.seg + (size_t)r * per + ft0;
-                if (ORDERED) { s_l = sp[wave]; e_l = sp[wave + 1]; }
-                else         { s_l = sp[0];    e_l = sp[NW]; }
+    for (int row = blockIdx.x; row < A.m; row += gridDim.x) {
+        const int a0 = A.a_ptr[row], a1 = A.a_ptr[row + 1];
+        const int64_t gi = row + A.row_offset;
+        int64_t rs = 0;
+        int cnt = 0;
+        if (OUT == OUT_SPARSE) {
+            rs = A.c_ptr[row];
+            cnt = (int)(A.c_ptr[row + 1] - rs);
+            if (cnt == 0) continue;                     // empty row of C (workgroup-uniform)
+        }
+        double *__restrict__ trow = OUT == OUT_SPARSE ? A.tbuf + (size_t)blockIdx.x * (size_t)A.ncols
+                                                      : A.c_dense + (int64_t)row * A.ldc;
+        int thresh = 0;
+        if (SYM) thresh = gi > 0x7fffffff ? 0x7fffffff : (int)gi;
+
+        for (int tc = 0; tc < A.nct; ++tc) {
+            const int lo_c = tc * A.wc;
+            const int w = (A.ncols - lo_c) < A.wc ? (A.ncols - lo_c) : A.wc;
+            if (w <= 0) break;
+            // a tile entirely left of the diagonal holds nothing under SMM_SYMMETRIC
+            const bool below = SYM && ((int64_t)lo_c + A.wc <= gi);
+            if (OUT == OUT_SPARSE && below) continue;
+            SMM_MARK();
+            for (int x = threadIdx.x; x < A.wc; x += NT) acc[x] = zero;
+            if (NW > 1) __syncthreads();
+            SMM_LAP(t_init);
+            if (!below && a1 > a0) {
+                if (EXACT) smm_accumulate<SYM>(A, acc, lo_c, thresh, a0, a1, tc * NW + wave);
+                else       smm_accumulate_shared<SYM, NW>(A, acc, lo_c, thresh, a0, a1, tc, wave);
             }
-            const int nb = (a1 - jb) < WAVE ? (a1 - jb) : WAVE;
-            const int jstep = ORDERED ? 1 : NW;
-            for (int jj = ORDERED ? 0 : wave; jj < nb; jj += jstep * NUM_UNROLL) {
-                int s[NUM_UNROLL], en[NUM_UNROLL], c[NUM_UNROLL];
-                double a[NUM_UNROLL], v[NUM_UNROLL];
-                bool p[NUM_UNROLL];
+            if (NW > 1) __syncthreads();
+            SMM_LAP(t_acc);
+            for (int x = threadIdx.x; x < w; x += NT) trow[lo_c + x] = acc[x];
+            if (NW > 1) __syncthreads();
+            SMM_LAP(t_flush);
+        }
+
+        if (OUT == OUT_SPARSE) {
+            // T was written by THIS workgroup and is read back by it: no other CU is involved, so
+            // no L2 write-back (an agent-scope release would flush the whole XCD's dirty L2 --
+            // measured: the gather phase took 58 % of the kernel with it).  It is enough that
+            // every wave's stores have been acknowledged by L2 (workgroup-scope release =
+            // s_waitcnt vmcnt(0)) before any wave reads; the reads bypass L1 (agent-scope relaxed
+            // loads = sc1), because a line of T cached by this CU's L1 during the previous row's
+            // gather would be stale now.
+            SMM_MARK();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            const int *__restrict__ list = A.tmp_idx + A.ub_off[row];
+            int *__restrict__ oi = A.c_idx + rs;
+            double *__restrict__ ov = A.c_val + rs;
+            constexpr int GU = 8;
+            for (int s0 = threadIdx.x; s0 < cnt; s0 += NT * GU) {
+                int c[GU];
+                double v[GU];
 #pragma unroll
-                for (int u = 0; u < NUM_UNROLL; ++u) {      // issue every first-chunk load
-                    const int j = jj + u * jstep;
-                    const int jc = j < WAVE ? j : WAVE - 1;
-                    s[u] = rl(s_l, jc); en[u] = rl(e_l, jc); a[u] = rl(av, jc);
-                    if (j >= nb) en[u] = s[u];
-                    const int k = s[u] + lane;
-                    p[u] = k < en[u];
-                    c[u] = p[u] ? A.b_idx[k] : 0;
-                    v[u] = p[u] ? A.b_val[k] : 0.0;
+                for (int u = 0; u < GU; ++u) {
+                    const int s = s0 + u * NT;
+                    c[u] = list[s < cnt ? s : cnt - 1];
                 }
 #pragma unroll
-                for (int u = 0; u < NUM_UNROLL; ++u) {      // then add, in A-entry order
-                    bool ok = p[u];
-                    if (SYM) ok = ok && ((int64_t)c[u] >= gi);
-                    if (ok) lds_add(&acc[c[u] - lo_c], a[u] * v[u]);
-                    for (int base = s[u] + WAVE; base < en[u]; base += WAVE) {   // long segments
-                        const int k = base + lane;
-                        if (k < en[u]) {
-                            const int c2 = A.b_idx[k];
-                            const double v2 = A.b_val[k];
-                            if (!SYM || (int64_t)c2 >= gi) lds_add(&acc[c2 - lo_c], a[u] * v2);
-                        }
-                    }
+                for (int u = 0; u < GU; ++u)
+                    v[u] = __hip_atomic_load(&trow[c[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int u = 0; u < GU; ++u) {
+                    const int s = s0 + u * NT;
+                    if (s < cnt) { oi[s] = c[u]; ov[s] = v[u]; }
                 }
             }
+            __syncthreads();        // the next row's tile stores must not overtake these loads
+            SMM_LAP(t_gather);
         }
     }
-    __syncthreads();
+#ifdef SMM_STAMPS
+    if (threadIdx.x == 0 && A.stamps) {
+        atomicAdd(&A.stamps[0], t_init); atomicAdd(&A.stamps[1], t_acc);
+        atomicAdd(&A.stamps[2], t_flush); atomicAdd(&A.stamps[3], t_gather);
+    }
+#endif
+#undef SMM_MARK
+#undef SMM_LAP
+}
 
-    if (OUT == OUT_DENSE) {
-        const int w = (A.ncols - lo_c) < A.wc ? (A.ncols - lo_c) : A.wc;
-        double *dst = A.c_dense + (int64_t)row * A.ldc + lo_c;
-        for (int x = threadIdx.x; x < w; x += NW * 64) dst[x] = acc[x];
-    } else {
-        const int per = A.nct + 1;
-        for (int jb = a0; jb < a1; jb += WAVE) {
-            const int e = jb + lane;
-            unsigned r0 = 0, r1 = 0;
-            if (e < a1) { const unsigned *r = A.runs + (size_t)e * per + tc; r0 = r[0]; r1 = r[1]; }
-            const int nb = (a1 - jb) < WAVE ? (a1 - jb) : WAVE;
-            for (int jj = wave; jj < nb; jj += NW) {
-                const unsigned s0 = rl(r0, jj), s1 = rl(r1, jj);
-                for (unsigned sl = s0 + lane; sl < s1; sl += WAVE) {
-                    const int c = A.c_idx[rs + sl];
-                    A.c_val[rs + sl] = acc[c - lo_c];
-                }
-            }
-        }
+// ---------------------------------------------------------------------------------------
+// Copy the ordered lists from their capacity-strided slots to the CSR index array (only the
+// general path below needs it; smm_numeric emits indices itself).
+__global__ __launch_bounds__(256) void smm_copy_lists(int m, const int64_t *__restrict__ ub_off,
+                                                      const int64_t *__restrict__ c_ptr,
+                                                      const int *__restrict__ tmp_idx,
+                                                      int *__restrict__ c_idx)
+{
+    for (int row = blockIdx.x; row < m; row += gridDim.x) {
+        const int64_t src = ub_off[row], dst = c_ptr[row];
+        const int n = (int)(c_ptr[row + 1] - dst);
+        for (int s = threadIdx.x; s < n; s += blockDim.x) c_idx[dst + s] = tmp_idx[src + s];
     }
 }
 

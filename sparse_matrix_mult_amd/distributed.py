@@ -102,7 +102,7 @@ def allgather_csr(indptr, indices, data, dist, group=None):
     return g_indptr, g_indices, g_data
 
 
-def spgemm_row_sharded(ctx, matrix_a, matrix_b, dist, symmetric=False, unordered=False, gather=True, group=None):
+def spgemm_row_sharded(ctx, matrix_a, matrix_b, dist, symmetric=False, gather=True, group=None, exact=False):
     """C = A @ B with A's rows sharded over the ranks of `group`; A and B are scipy CSR
     matrices every rank holds (the replicated-input case of SURVEY 8e).  Returns torch
     tensors on this rank's GPU: the whole CSR when gather=True, else this rank's row block
@@ -120,7 +120,7 @@ def spgemm_row_sharded(ctx, matrix_a, matrix_b, dist, symmetric=False, unordered
         r0, r1 = shards[rank] if rank < len(shards) else (matrix_a.shape[0], matrix_a.shape[0])
         a = ctx.csr_from_scipy(matrix_a[r0:r1])
         try:
-            indptr, indices, data = ctx.spgemm_torch(a, b, symmetric=symmetric, unordered=unordered, row_offset=r0)
+            indptr, indices, data = ctx.spgemm_torch(a, b, symmetric=symmetric, row_offset=r0, exact=exact)
         finally:
             a.close()
     finally:

@@ -9,10 +9,14 @@ import threading
 
 import numpy as np
 
-from ._lib import (SMM_FULL_MATRIX, SMM_SYMMETRIC, SMM_UNORDERED, SmmError, SmmLibrary, check)
+from ._lib import SMM_EXACT, SMM_FULL_MATRIX, SMM_SYMMETRIC, SmmError, SmmLibrary, check
 
 __all__ = ["Context", "DeviceCSR", "default_context", "SmmError",
-           "SMM_SYMMETRIC", "SMM_FULL_MATRIX", "SMM_UNORDERED"]
+           "SMM_SYMMETRIC", "SMM_FULL_MATRIX", "SMM_EXACT"]
+
+
+def _flags(symmetric=False, exact=False, full=False):
+    return (SMM_SYMMETRIC if symmetric else 0) | (SMM_EXACT if exact else 0) | (SMM_FULL_MATRIX if full else 0)
 
 
 def _ptr(arr):
@@ -45,7 +49,12 @@ class Context:
         check(self.lib, self.lib.smm_ctx_synchronize(self.handle))
 
     def tune(self, lds_cols=0, waves=0):
+        """Geometry of the SMM_EXACT walk (waves 1/2/4/8)."""
         check(self.lib, self.lib.smm_ctx_tune(self.handle, int(lds_cols), int(waves)))
+
+    def tune_shared(self, lds_cols=0, waves=0):
+        """Geometry of the default shared-tile walk (waves 4/8/16)."""
+        check(self.lib, self.lib.smm_ctx_tune_shared(self.handle, int(lds_cols), int(waves)))
 
     def timing(self, enable=True):
         check(self.lib, self.lib.smm_ctx_timing(self.handle, 1 if enable else 0))
@@ -92,16 +101,16 @@ class Context:
         return out
 
     # ------------------------------------------------------------------ CSR x CSR -> CSR
-    def spgemm_plan(self, a, b, symmetric=False, unordered=False, row_offset=0):
-        flags = (SMM_SYMMETRIC if symmetric else 0) | (SMM_UNORDERED if unordered else 0)
+    def spgemm_plan(self, a, b, symmetric=False, row_offset=0, exact=False):
+        flags = _flags(symmetric, exact)
         plan, nnz = ctypes.c_void_p(), ctypes.c_int64()
         check(self.lib, self.lib.smm_spgemm_symbolic(self.handle, a.handle, b.handle, flags, int(row_offset),
                                                      ctypes.byref(plan), ctypes.byref(nnz)))
         return Plan(self, plan, a, b, nnz.value)
 
-    def spgemm_host(self, a, b, symmetric=False, unordered=False, row_offset=0):
+    def spgemm_host(self, a, b, symmetric=False, row_offset=0, exact=False):
         """(indptr int64, indices int32, data float64) numpy arrays, reference (first-touch) order."""
-        plan = self.spgemm_plan(a, b, symmetric, unordered, row_offset)
+        plan = self.spgemm_plan(a, b, symmetric, row_offset, exact)
         try:
             indptr = np.empty(a.rows + 1, dtype=np.int64)
             indices = np.empty(plan.nnz, dtype=np.int32)
@@ -112,10 +121,10 @@ class Context:
             plan.close()
         return indptr, indices, data
 
-    def spgemm_torch(self, a, b, symmetric=False, unordered=False, row_offset=0):
+    def spgemm_torch(self, a, b, symmetric=False, row_offset=0, exact=False):
         """Same product with the result left in HBM as torch tensors (indptr int64)."""
         import torch
-        plan = self.spgemm_plan(a, b, symmetric, unordered, row_offset)
+        plan = self.spgemm_plan(a, b, symmetric, row_offset, exact)
         try:
             dev = torch.device("cuda", self.device)
             indptr = torch.empty(a.rows + 1, dtype=torch.int64, device=dev)
@@ -127,30 +136,29 @@ class Context:
         return indptr, indices, data
 
     # ------------------------------------------------------------------ CSR x CSR -> dense
-    def dense_host(self, a, b, symmetric=False, unordered=False, row_offset=0):
-        flags = (SMM_SYMMETRIC if symmetric else 0) | (SMM_UNORDERED if unordered else 0)
+    def dense_host(self, a, b, symmetric=False, row_offset=0, exact=False):
+        flags = _flags(symmetric, exact)
         out = np.empty((a.rows, b.cols), dtype=np.float64)
         check(self.lib, self.lib.smm_spgemm_dense_host(self.handle, a.handle, b.handle, flags, int(row_offset),
                                                        _ptr(out)))
         return out
 
-    def dense_into(self, a, b, d_ptr, symmetric=False, unordered=False, row_offset=0):
-        flags = (SMM_SYMMETRIC if symmetric else 0) | (SMM_UNORDERED if unordered else 0)
+    def dense_into(self, a, b, d_ptr, symmetric=False, row_offset=0, exact=False):
+        flags = _flags(symmetric, exact)
         check(self.lib, self.lib.smm_spgemm_dense(self.handle, a.handle, b.handle, flags, int(row_offset),
                                                   ctypes.c_void_p(d_ptr)))
 
     # ------------------------------------------------------------------ H Q H^T
-    def triple_host(self, h, q, full=False, row_begin=0, row_end=None):
+    def triple_host(self, h, q, full=False, row_begin=0, row_end=None, exact=False):
         row_end = h.rows if row_end is None else row_end
         out = np.empty((row_end - row_begin, h.rows), dtype=np.float64)
-        check(self.lib, self.lib.smm_triple_product_host(self.handle, h.handle, q.handle,
-                                                         SMM_FULL_MATRIX if full else 0, int(row_begin), int(row_end),
-                                                         _ptr(out)))
+        check(self.lib, self.lib.smm_triple_product_host(self.handle, h.handle, q.handle, _flags(False, exact, full),
+                                                         int(row_begin), int(row_end), _ptr(out)))
         return out
 
-    def triple_into(self, h, q, d_ptr, full=False, row_begin=0, row_end=None):
+    def triple_into(self, h, q, d_ptr, full=False, row_begin=0, row_end=None, exact=False):
         row_end = h.rows if row_end is None else row_end
-        check(self.lib, self.lib.smm_triple_product(self.handle, h.handle, q.handle, SMM_FULL_MATRIX if full else 0,
+        check(self.lib, self.lib.smm_triple_product(self.handle, h.handle, q.handle, _flags(False, exact, full),
                                                     int(row_begin), int(row_end), ctypes.c_void_p(d_ptr)))
 
 

@@ -12,12 +12,27 @@ same argument meaning, same return types, same raised errors.  What differs:
     one swallowed case the reference's callers can observe on purpose, an unknown
     output_format, is kept: message printed, zeros returned.
 """
+import os
+
 import numpy as np
 from scipy.sparse import csr_matrix, isspmatrix_csr
 
 from .engine import default_context
 
 _INT32_MAX = np.iinfo(np.int32).max
+
+# SMM_EXACT=1 (or set_exact(True)): add products in exactly the reference's order, so float64
+# values are bit-identical to the reference's loop; the default lets the waves of a workgroup
+# add concurrently -- values agree to rounding (tested to 1e-10 relative), ~3x faster.
+# indptr / indices are bit-exact either way.
+_exact = os.environ.get("SMM_EXACT", "0") not in ("", "0")
+
+
+def set_exact(flag):
+    """Select bit-exact (reference-order) accumulation for later calls; returns the old setting."""
+    global _exact
+    old, _exact = _exact, bool(flag)
+    return old
 
 
 def _as_csr(x):
@@ -90,12 +105,12 @@ def sparse_matrix_multiply(matrix_a, matrix_b, output_format='sparse', symmetric
     b = ctx.csr_from_scipy(matrix_b)
     try:
         if use_triple_product:                               # reference :325-336
-            result = ctx.triple_host(a, b, full=bool(compute_full_matrix))
+            result = ctx.triple_host(a, b, full=bool(compute_full_matrix), exact=_exact)
         elif output_format == 'sparse':                      # reference :338-351
-            indptr, indices, data = ctx.spgemm_host(a, b, symmetric=bool(symmetric))
+            indptr, indices, data = ctx.spgemm_host(a, b, symmetric=bool(symmetric), exact=_exact)
             result = _result_csr(indptr, indices, data, out_shape)
         else:                                                # reference :353-365
-            result = ctx.dense_host(a, b, symmetric=bool(symmetric))
+            result = ctx.dense_host(a, b, symmetric=bool(symmetric), exact=_exact)
     finally:
         a.close()
         b.close()
