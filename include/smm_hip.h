@@ -67,8 +67,8 @@ int  smm_ctx_timing(smm_ctx *ctx, int enable);
 int  smm_ctx_timing_reset(smm_ctx *ctx);
 int  smm_ctx_kernel_time(smm_ctx *ctx, const char *kernel, double *ms_total, int64_t *launches);
 /* Tuning knobs (0 keeps the default): LDS accumulator columns per workgroup (x 8 bytes of
- * LDS; default 5000 = four workgroups per CU) and waves per workgroup (1, 2, 4 or 8) of the
- * numeric kernels.  Results do not depend on them, bit for bit. */
+ * LDS; default 20000 = one workgroup per CU) and waves per workgroup of the numeric kernels.
+ * In SMM_EXACT mode results do not depend on them, bit for bit. */
 int  smm_ctx_tune(smm_ctx *ctx, int lds_cols, int waves);             /* SMM_EXACT walk          */
 int  smm_ctx_tune_shared(smm_ctx *ctx, int lds_cols, int waves);      /* default walk (4/8/16)   */
 

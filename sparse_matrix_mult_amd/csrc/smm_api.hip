@@ -57,9 +57,9 @@ struct smm_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool timing = false;
-    int lds_cols = 5000;     // accumulator columns per workgroup (x8 B of LDS: 4 workgroups per CU)
-    int waves = 1;           // waves per numeric workgroup
-    int lds_cols_shared = 16384;   // default (shared-tile) walk: tile columns and waves per workgroup
+    int lds_cols = 20000;    // SMM_EXACT walk: accumulator columns per workgroup (x8 B of LDS) ...
+    int waves = 8;           // ... and waves per workgroup (each owns lds_cols/waves columns)
+    int lds_cols_shared = 20000;   // default (shared-tile) walk: tile columns and waves per workgroup
     int waves_shared = 16;
     int seg_target = 40;     // aimed-at entries of B per (row of B, fine tile) segment; <= 64 lanes
     int n_cu = 256;
@@ -459,14 +459,8 @@ static int launch_numeric_t(smm_ctx *c, NumericArgs &args)
     auto kern = smm_numeric<OUT, SYM, NW, EXACT>;
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // persistent workgroups: as many as the LDS lets a CU hold (x CUs), never more than rows
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)(160 * 1024) / std::max<size_t>(lds, 1), 32 / NW));
-    const int grid = (int)std::min<int64_t>((int64_t)c->n_cu * per_cu, args.m);
-    double *tbuf = nullptr;
-    if (OUT == OUT_SPARSE) {
-        CHK(pool_get(c, (size_t)grid * (size_t)args.ncols, &tbuf));
-        args.tbuf = tbuf;
-    }
+    const int64_t grid = (int64_t)args.m * args.nct;
+    if (grid > 0x7fffffff) return fail(SMM_ERR_INVALID, "too many (row, tile) units for one launch");
 #ifdef SMM_STAMPS
     unsigned long long *d_st = nullptr;
     CHK(pool_get(c, 4, &d_st));
@@ -480,15 +474,12 @@ static int launch_numeric_t(smm_ctx *c, NumericArgs &args)
         unsigned long long h[4];
         (void)hipMemcpyAsync(h, d_st, 32, hipMemcpyDeviceToHost, c->stream);
         (void)hipStreamSynchronize(c->stream);
-        const double tot = (double)(h[0] + h[1] + h[2] + h[3]);
-        fprintf(stderr, "[SMM_STAMPS] grid=%d NW=%d wc=%d nct=%d  init %.1f%%  accumulate %.1f%%  flush %.1f%%  gather %.1f%%  (sum %.3g cycles, %.3g per workgroup)\n",
-                grid, NW, args.wc, args.nct, 100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, tot, tot / grid);
+        const double tot = (double)(h[0] + h[1] + h[2]);
+        fprintf(stderr, "[SMM_STAMPS] units=%lld NW=%d wc=%d nct=%d exact=%d  init %.1f%%  accumulate %.1f%%  epilogue %.1f%%  (sum %.3g cycles)\n",
+                (long long)grid, NW, args.wc, args.nct, (int)EXACT, 100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, tot);
         pool_free(c, d_st);
     }
 #endif
-    if (tbuf) {                                 // stream-ordered reuse: the pool is per context/stream
-        pool_free(c, tbuf);
-    }
     if (e != hipSuccess) return fail(SMM_ERR_HIP, "smm_numeric launch: %s", hipGetErrorString(e));
     return SMM_OK;
 }
@@ -519,6 +510,8 @@ struct smm_plan {
     Geom g{};
     int64_t *d_ub_off = nullptr;   // m+1
     int *d_tmp = nullptr;          // capacity-strided ordered column lists
+    unsigned *d_P = nullptr;       // nnz(A)
+    unsigned *d_runs = nullptr;    // nnz(A) x (nct+1)
     int *d_rowcnt = nullptr;       // m
     int64_t *d_cptr = nullptr;     // m+1
 };
@@ -529,7 +522,7 @@ extern "C" void smm_plan_destroy(smm_plan *p)
     smm_ctx *c = p->ctx;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    pool_free(c, p->d_ub_off); pool_free(c, p->d_tmp);
+    pool_free(c, p->d_ub_off); pool_free(c, p->d_tmp); pool_free(c, p->d_P); pool_free(c, p->d_runs);
     pool_free(c, p->d_rowcnt); pool_free(c, p->d_cptr);
     delete p;
 }
@@ -543,7 +536,7 @@ static int launch_symbolic_t(smm_ctx *c, smm_plan *p, int bm_words, unsigned *gb
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     LAUNCH(c, "smm_symbolic", kern, grid, 256, lds, (int)p->m, p->row_offset, bm_words, p->a->ptr, p->a->idx,
-           p->b->ptr, p->b->idx, p->d_ub_off, p->d_tmp, p->d_rowcnt, gbm,
+           p->b->ptr, p->b->idx, p->d_ub_off, p->d_tmp, p->d_P, p->d_rowcnt, gbm,
            (const int *)((const char *)c->d_flags + 64));
     LAUNCH_CHECK();
     return SMM_OK;
@@ -593,6 +586,7 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     }
     pool_free(c, d_prod); pool_free(c, d_ub);
     PCHK(pool_get(c, (size_t)std::max<int64_t>(total_ub, 1), &p->d_tmp));
+    PCHK(pool_get(c, (size_t)a->nnz, &p->d_P));
     PCHK(pool_get(c, (size_t)m, &p->d_rowcnt));
 
     // symbolic: one wave per row, 4 rows per workgroup
@@ -614,7 +608,15 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "symbolic phase: %s", hipGetErrorString(e)); }
     }
     if (gbm) pool_free(c, gbm);
-    if (p->b_sorted && p->nnz > 0) PCHK(ensure_seg(c, b, p->g));
+    if (p->b_sorted && p->nnz > 0) {
+        PCHK(ensure_seg(c, b, p->g));
+        PCHK(pool_get(c, (size_t)a->nnz * (p->g.nct + 1), &p->d_runs));
+        const int rgrid = (int)std::min<int64_t>((m + 3) / 4, 65536);
+        LAUNCH(c, "smm_runs", smm_runs, rgrid, 256, 0, (int)m, p->g.nct, p->g.wc, a->ptr, p->d_ub_off, p->d_rowcnt,
+               p->d_P, p->d_tmp, p->d_runs);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "smm_runs: %s", hipGetErrorString(e)); }
+    }
 #undef PCHK
     if (nnz_out) *nnz_out = p->nnz;
     *plan = p;
@@ -639,7 +641,7 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
         A.a_ptr = p->a->ptr; A.a_idx = p->a->idx; A.a_val = p->a->val;
         A.b_idx = p->b->idx; A.b_val = p->b->val; A.seg = p->b->seg;
         A.c_ptr = p->d_cptr; A.c_idx = d_c_indices; A.c_val = d_c_data;
-        A.ub_off = p->d_ub_off; A.tmp_idx = p->d_tmp;
+        A.ub_off = p->d_ub_off; A.tmp_idx = p->d_tmp; A.runs = p->d_runs;
         CHK(launch_numeric<OUT_SPARSE>(c, A, sym, p->g.nw, (p->flags & SMM_EXACT) != 0));
     } else {
         const int cgrid = (int)std::min<int64_t>(m, 65536);

@@ -176,6 +176,7 @@ __global__ __launch_bounds__(1024) void smm_scan(int n, const T *__restrict__ in
 // order, append a column the first time it is seen.  One wave per row; the marker is a
 // bitmap of B's columns (LDS when it fits, else a global slab per wave).
 //   tmp_idx + ub_off[row] : the row's ordered column list (capacity ub[row])
+//   P[e]                  : number of columns already in the list when A entry e starts
 //   rowcnt[row]           : final length = nnz of the row of C
 // SAFE resolves two lanes of one wave-instruction hitting the same column (possible only
 // when a row of B repeats a column): the LOWEST lane must win, whatever the LDS picks.
@@ -192,6 +193,7 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, i
                                                     const int *__restrict__ b_idx,
                                                     const int64_t *__restrict__ ub_off,
                                                     int *__restrict__ tmp_idx,
+                                                    unsigned *__restrict__ P,
                                                     int *__restrict__ rowcnt,
                                                     unsigned *__restrict__ gbitmap,
                                                     const int *__restrict__ dummy_idx)
@@ -228,8 +230,9 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, i
                     if (lane >= o) incl += y;
                 }
                 const int total = rl(incl, WAVE - 1);
+                unsigned myP = 0xffffffffu;                             // unset: entry without chunks
                 for (int t0 = 0; t0 < total; t0 += SYM_UNROLL) {
-                    int c[SYM_UNROLL];
+                    int c[SYM_UNROLL], owner[SYM_UNROLL];
 #pragma unroll
                     for (int u = 0; u < SYM_UNROLL; ++u) {              // all loads first (MLP)
                         const int t = t0 + u;
@@ -241,9 +244,11 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, i
                         const bool p = t < total && k < en;
                         const int *ip = p ? b_idx + k : dummy_idx;
                         c[u] = *ip;
+                        owner[u] = (t < total && t == first) ? j : -1;  // first chunk of entry j
                     }
 #pragma unroll
                     for (int u = 0; u < SYM_UNROLL; ++u) {              // then consume in order
+                        if (lane == owner[u]) myP = (unsigned)n;
                         const bool a = c[u] >= thresh;                  // also drops the dummy -1
                         const unsigned bit = 1u << (c[u] & 31);
                         unsigned *wp = bm + (a ? (c[u] >> 5) : 0);
@@ -272,6 +277,17 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, i
                         n += __popcll(mask);
                     }
                 }
+                // an entry whose row of B is empty starts where the next one starts
+                {
+                    unsigned v = myP;
+#pragma unroll
+                    for (int o = 1; o < WAVE; o <<= 1) {
+                        const unsigned y = __shfl_down(v, o);
+                        if (lane + o < WAVE && y < v) v = y;
+                    }
+                    if (v == 0xffffffffu) v = (unsigned)n;
+                    if (lane < nb) P[jb + lane] = v;
+                }
                 bs = bs_n; be = be_n; r_n = r_nn;
             }
         }
@@ -289,18 +305,56 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, i
 }
 
 // ---------------------------------------------------------------------------------------
-// Numeric phase.  A workgroup of NW waves owns one ROW of C at a time (persistent, grid-stride)
-// and walks its coarse tiles; LDS = one coarse tile of wc f64 accumulators.
-//   per tile : accumulators := zero; smm_accumulate (below); tile -> HBM row buffer
-//   OUT_DENSE : the row buffer is the row of C itself (zero = +0.0: calloc,
-//               sparse_sparse_dense.cpp:97).
-//   OUT_SPARSE: the row buffer is a per-workgroup scratch row T (zero = -0.0, the additive
-//               identity: -0.0 + p == p bit for bit, which reproduces `values[index] = p` of
-//               sparsework.cpp:108-109).  After the last tile the workgroup emits the row in
-//               the reference's first-touch order: for slot s, c = list[s] (smm_symbolic),
-//               indices[s] = c, values[s] = T[c].  T is 8*ncols bytes per resident workgroup
-//               (256-1024 of them): it lives in L2 / Infinity Cache between the tile stores
-//               and the gather, so HBM sees the CSR output once, fully coalesced.
+// Sub-run table.  Step e of a row appended the columns list[P[e] .. P[e+1]) in ascending
+// order (B's rows are sorted), so the part that falls into coarse tile t is the contiguous
+// slot range [runs[e][t], runs[e][t+1]).  One lane per A entry, nct-1 lower_bounds each.
+__global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc,
+                                                const int *__restrict__ a_ptr,
+                                                const int64_t *__restrict__ ub_off,
+                                                const int *__restrict__ rowcnt,
+                                                const unsigned *__restrict__ P,
+                                                const int *__restrict__ tmp_idx,
+                                                unsigned *__restrict__ runs)
+{
+    const int lane = lane_id();
+    const int wpb = blockDim.x / WAVE;
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < m; row += gridDim.x * wpb) {
+        const int a0 = a_ptr[row], a1 = a_ptr[row + 1];
+        const int *__restrict__ list = tmp_idx + ub_off[row];
+        const unsigned total = (unsigned)rowcnt[row];
+        for (int e = a0 + lane; e < a1; e += WAVE) {
+            const unsigned p0 = P[e];
+            const unsigned p1 = (e + 1 < a1) ? P[e + 1] : total;
+            unsigned *r = runs + (size_t)e * (nct + 1);
+            r[0] = p0;
+            unsigned lo = p0;
+            for (int t = 1; t < nct; ++t) {
+                const int64_t bound = (int64_t)t * wc;
+                unsigned hi = p1;
+                while (lo < hi) {
+                    const unsigned mid = lo + ((hi - lo) >> 1);
+                    if ((int64_t)list[mid] < bound) lo = mid + 1; else hi = mid;
+                }
+                r[t] = lo;
+            }
+            r[nct] = p1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Numeric phase.  Workgroup = one (row, coarse tile) unit, tile-major so that concurrent
+// units read the same column slab of B; NW waves; LDS = wc f64 accumulators.
+//   OUT_DENSE : accumulators start at +0.0 (calloc, sparse_sparse_dense.cpp:97); the tile is
+//               written to C[row, lo..hi).
+//   OUT_SPARSE: accumulators start at -0.0 (the additive identity: -0.0 + p == p bit for bit,
+//               which reproduces `values[index] = p` of sparsework.cpp:108-109).  The epilogue
+//               emits the tile's share of the row in the reference's first-touch order: step e
+//               of the row put its new columns into slots [runs[e][t], runs[e][t+1]) -- a
+//               contiguous sub-run -- so indices and values go out as short contiguous runs
+//               straight from LDS (no per-element traffic through L2: a first version that
+//               staged the row in an L2-resident scratch row and gathered 8-byte elements from
+//               it spent half the kernel on those 2.5e9 L2 requests).
 // Two walks fill a tile:
 //   EXACT (SMM_EXACT): wave w owns fine tile w (columns [lo_c + w*wf, +wf)) and visits every A
 //     entry of the row in stored order, so every accumulator receives its products in exactly
@@ -327,7 +381,7 @@ struct NumericArgs {
     // sparse output
     const int64_t *c_ptr; int *c_idx; double *c_val;
     const int64_t *ub_off; const int *tmp_idx;   // ordered column lists of smm_symbolic
-    double *tbuf;                   // gridDim.x scratch rows of ncols doubles
+    const unsigned *runs;           // [nnzA][nct+1] sub-run table (smm_runs)
     unsigned long long *stamps;     // diagnostic builds (-DSMM_STAMPS) only: 4 phase totals
     // dense output
     double *c_dense; int64_t ldc;
@@ -527,101 +581,100 @@ __device__ __forceinline__ void smm_accumulate_shared(const NumericArgs &A, doub
     }
 }
 
+constexpr int EPI_UNROLL = 4;
+
 template <int OUT, bool SYM, int NW, bool EXACT>
 __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
 {
     extern __shared__ double acc[];
+    const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     constexpr int NT = NW * 64;
     const double zero = OUT == OUT_SPARSE ? -0.0 : 0.0;
 #ifdef SMM_STAMPS
-    // Diagnostic build only (never the shipped library): wave 0 sums the cycles of each phase and
-    // adds them to a buffer nothing else reads.
-    unsigned long long t_init = 0, t_acc = 0, t_flush = 0, t_gather = 0, t_mark;
+    // Diagnostic build only (never the shipped library): thread 0 sums the cycles of each phase
+    // and adds them to a buffer nothing else reads.
+    unsigned long long t_init = 0, t_acc = 0, t_epi = 0, t_mark;
 #define SMM_MARK() (t_mark = __builtin_readcyclecounter())
 #define SMM_LAP(var) { const unsigned long long now_ = __builtin_readcyclecounter(); var += now_ - t_mark; t_mark = now_; }
 #else
 #define SMM_MARK()
 #define SMM_LAP(var)
 #endif
+    const int tc = blockIdx.x / A.m;            // tile-major: concurrent units share B's slab
+    const int row = blockIdx.x - tc * A.m;
+    const int a0 = A.a_ptr[row], a1 = A.a_ptr[row + 1];
+    const int64_t gi = row + A.row_offset;
+    const int lo_c = tc * A.wc;
+    const int w = (A.ncols - lo_c) < A.wc ? (A.ncols - lo_c) : A.wc;
+    if (w <= 0) return;
+    int64_t rs = 0;
+    if (OUT == OUT_SPARSE) {
+        rs = A.c_ptr[row];
+        if (A.c_ptr[row + 1] == rs) return;             // empty row of C (workgroup-uniform)
+    }
+    // a tile entirely left of the diagonal holds nothing under SMM_SYMMETRIC
+    const bool below = SYM && ((int64_t)lo_c + A.wc <= gi);
+    if (OUT == OUT_SPARSE && below) return;
+    int thresh = 0;
+    if (SYM) thresh = gi > 0x7fffffff ? 0x7fffffff : (int)gi;
 
-    for (int row = blockIdx.x; row < A.m; row += gridDim.x) {
-        const int a0 = A.a_ptr[row], a1 = A.a_ptr[row + 1];
-        const int64_t gi = row + A.row_offset;
-        int64_t rs = 0;
-        int cnt = 0;
-        if (OUT == OUT_SPARSE) {
-            rs = A.c_ptr[row];
-            cnt = (int)(A.c_ptr[row + 1] - rs);
-            if (cnt == 0) continue;                     // empty row of C (workgroup-uniform)
-        }
-        double *__restrict__ trow = OUT == OUT_SPARSE ? A.tbuf + (size_t)blockIdx.x * (size_t)A.ncols
-                                                      : A.c_dense + (int64_t)row * A.ldc;
-        int thresh = 0;
-        if (SYM) thresh = gi > 0x7fffffff ? 0x7fffffff : (int)gi;
+    SMM_MARK();
+    for (int x = threadIdx.x; x < A.wc; x += NT) acc[x] = zero;
+    if (NW > 1) __syncthreads();
+    SMM_LAP(t_init);
+    if (!below && a1 > a0) {
+        if (EXACT) smm_accumulate<SYM>(A, acc, lo_c, thresh, a0, a1, tc * NW + wave);
+        else       smm_accumulate_shared<SYM, NW>(A, acc, lo_c, thresh, a0, a1, tc, wave);
+    }
+    if (NW > 1) __syncthreads();
+    SMM_LAP(t_acc);
 
-        for (int tc = 0; tc < A.nct; ++tc) {
-            const int lo_c = tc * A.wc;
-            const int w = (A.ncols - lo_c) < A.wc ? (A.ncols - lo_c) : A.wc;
-            if (w <= 0) break;
-            // a tile entirely left of the diagonal holds nothing under SMM_SYMMETRIC
-            const bool below = SYM && ((int64_t)lo_c + A.wc <= gi);
-            if (OUT == OUT_SPARSE && below) continue;
-            SMM_MARK();
-            for (int x = threadIdx.x; x < A.wc; x += NT) acc[x] = zero;
-            if (NW > 1) __syncthreads();
-            SMM_LAP(t_init);
-            if (!below && a1 > a0) {
-                if (EXACT) smm_accumulate<SYM>(A, acc, lo_c, thresh, a0, a1, tc * NW + wave);
-                else       smm_accumulate_shared<SYM, NW>(A, acc, lo_c, thresh, a0, a1, tc, wave);
-            }
-            if (NW > 1) __syncthreads();
-            SMM_LAP(t_acc);
-            for (int x = threadIdx.x; x < w; x += NT) trow[lo_c + x] = acc[x];
-            if (NW > 1) __syncthreads();
-            SMM_LAP(t_flush);
-        }
-
-        if (OUT == OUT_SPARSE) {
-            // T was written by THIS workgroup and is read back by it: no other CU is involved, so
-            // no L2 write-back (an agent-scope release would flush the whole XCD's dirty L2 --
-            // measured: the gather phase took 58 % of the kernel with it).  It is enough that
-            // every wave's stores have been acknowledged by L2 (workgroup-scope release =
-            // s_waitcnt vmcnt(0)) before any wave reads; the reads bypass L1 (agent-scope relaxed
-            // loads = sc1), because a line of T cached by this CU's L1 during the previous row's
-            // gather would be stale now.
-            SMM_MARK();
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __syncthreads();
-            const int *__restrict__ list = A.tmp_idx + A.ub_off[row];
-            int *__restrict__ oi = A.c_idx + rs;
-            double *__restrict__ ov = A.c_val + rs;
-            constexpr int GU = 8;
-            for (int s0 = threadIdx.x; s0 < cnt; s0 += NT * GU) {
-                int c[GU];
-                double v[GU];
+    if (OUT == OUT_DENSE) {
+        double *__restrict__ dst = A.c_dense + (int64_t)row * A.ldc + lo_c;
+        for (int x = threadIdx.x; x < w; x += NT) dst[x] = acc[x];
+    } else {
+        const int *__restrict__ list = A.tmp_idx + A.ub_off[row];
+        int *__restrict__ oi = A.c_idx + rs;
+        double *__restrict__ ov = A.c_val + rs;
+        const size_t per = (size_t)A.nct + 1;
+        for (int jb = a0; jb < a1; jb += WAVE) {
+            int e = jb + lane;
+            e = e < a1 ? e : a1 - 1;
+            const unsigned *rp = A.runs + (size_t)e * per + tc;
+            const unsigned r0 = rp[0], r1 = rp[1];
+            const int nb = (a1 - jb) < WAVE ? (a1 - jb) : WAVE;
+            for (int jj = wave; jj < nb; jj += NW * EPI_UNROLL) {
+                int c[EPI_UNROLL];
+                unsigned sl[EPI_UNROLL], s1[EPI_UNROLL];
 #pragma unroll
-                for (int u = 0; u < GU; ++u) {
-                    const int s = s0 + u * NT;
-                    c[u] = list[s < cnt ? s : cnt - 1];
+                for (int u = 0; u < EPI_UNROLL; ++u) {          // first chunk of EPI_UNROLL sub-runs
+                    const int j = jj + u * NW;
+                    const int jc = j < WAVE ? j : WAVE - 1;
+                    const unsigned s0 = rl(r0, jc);
+                    s1[u] = j < nb ? rl(r1, jc) : s0;
+                    sl[u] = s0 + (unsigned)lane;
+                    const int *ip = sl[u] < s1[u] ? list + sl[u] : A.dummy_idx;
+                    c[u] = *ip;
                 }
 #pragma unroll
-                for (int u = 0; u < GU; ++u)
-                    v[u] = __hip_atomic_load(&trow[c[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int u = 0; u < GU; ++u) {
-                    const int s = s0 + u * NT;
-                    if (s < cnt) { oi[s] = c[u]; ov[s] = v[u]; }
+                for (int u = 0; u < EPI_UNROLL; ++u) {
+                    if (c[u] >= 0) { oi[sl[u]] = c[u]; ov[sl[u]] = acc[c[u] - lo_c]; }
+                    for (unsigned base = sl[u] + WAVE; base - lane < s1[u]; base += WAVE) {   // long sub-runs
+                        if (base < s1[u]) {
+                            const int c2 = list[base];
+                            oi[base] = c2;
+                            ov[base] = acc[c2 - lo_c];
+                        }
+                    }
                 }
             }
-            __syncthreads();        // the next row's tile stores must not overtake these loads
-            SMM_LAP(t_gather);
         }
     }
+    SMM_LAP(t_epi);
 #ifdef SMM_STAMPS
     if (threadIdx.x == 0 && A.stamps) {
-        atomicAdd(&A.stamps[0], t_init); atomicAdd(&A.stamps[1], t_acc);
-        atomicAdd(&A.stamps[2], t_flush); atomicAdd(&A.stamps[3], t_gather);
+        atomicAdd(&A.stamps[0], t_init); atomicAdd(&A.stamps[1], t_acc); atomicAdd(&A.stamps[2], t_epi);
     }
 #endif
 #undef SMM_MARK

@@ -67,7 +67,7 @@ def test_sparse_tile_geometries(ctx, oracle, lds_cols, waves):
     try:
         assert_csr_equal(_gpu_sparse(ctx, A, B, exact=True), want, values="bits")
     finally:
-        ctx.tune(5000, 1)
+        ctx.tune(20000, 8)
 
 
 @pytest.mark.parametrize("lds_cols,waves", [(64, 4), (300, 8), (1000, 16), (16384, 16), (20000, 8)])
@@ -79,7 +79,7 @@ def test_sparse_shared_tile_geometries(ctx, oracle, lds_cols, waves):
     try:
         got = _gpu_sparse(ctx, A, B)
     finally:
-        ctx.tune_shared(16384, 16)
+        ctx.tune_shared(20000, 16)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     assert np.allclose(got[2], want[2], rtol=1e-10, atol=1e-13)
 
