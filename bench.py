@@ -167,6 +167,15 @@ def main():
         total_nnz = float(nnz_c)
 
     if rank == 0:
+        # HBM traffic of the dominant kernel, from the committed PMC passes of this same workload
+        # (rocprofv3 cannot run inside the bench; profiles/traffic_r1.json says how it was taken)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r1.json")))
+            if (m, n, d) == (50000, 50000, 0.01) and not args.exact and not (args.lds_cols or args.waves):
+                traffic = tj["traffic_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         # compulsory one-touch bytes of one product
         alg_bytes = (4 * (m + 1) + 12 * nnz_a) + (4 * (n + 1) + 12 * nnz_b) + (8 * (m + 1) + 12 * nnz_c)
         num_avg_s = (num_ms / max(num_n, 1)) * 1e-3
@@ -186,7 +195,7 @@ def main():
                                else "default (indices bit-exact, values to rounding)",
                        "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "smm_numeric", "kernel_ms": num_ms / max(num_n, 1),
                          "algorithmic_bytes": alg_bytes,
                          "symbolic_kernel_ms": sym_ms / max(sym_n, 1)},
