@@ -276,6 +276,7 @@ struct smm_csr {
     unsigned vflags = 0;
     // cached tile index (sorted operands only)
     int *seg = nullptr; int seg_wf = 0, seg_nft = 0;
+    short *loc = nullptr; int loc_wc = 0;      // tile-local columns for coarse width loc_wc
 };
 
 static int validate(smm_ctx *c, smm_csr *m)
@@ -358,6 +359,7 @@ extern "C" void smm_csr_destroy(smm_csr *m)
     (void)hipStreamSynchronize(m->ctx->stream);
     if (m->owned) { (void)hipFree((void *)m->ptr); (void)hipFree((void *)m->idx); (void)hipFree((void *)m->val); }
     if (m->seg) (void)hipFree(m->seg);
+    if (m->loc) (void)hipFree(m->loc);
     delete m;
 }
 extern "C" int64_t smm_csr_rows(const smm_csr *m) { return m ? m->rows : -1; }
@@ -418,6 +420,22 @@ static int ensure_seg(smm_ctx *c, smm_csr *b, const Geom &g)
         LAUNCH_CHECK();
     }
     b->seg_wf = g.wf; b->seg_nft = g.n_ft;
+    return SMM_OK;
+}
+
+static int ensure_loc(smm_ctx *c, smm_csr *b, const Geom &g)
+{
+    if (b->loc && b->loc_wc == g.wc) return SMM_OK;
+    if (g.wc > 32767) return fail(SMM_ERR_INVALID, "coarse tile wider than 32767 columns");
+    if (b->loc) { HIPCHK(hipStreamSynchronize(c->stream)); (void)hipFree(b->loc); b->loc = nullptr; }
+    if (hipMalloc((void **)&b->loc, std::max<int64_t>(b->nnz, 1) * sizeof(short)) != hipSuccess)
+        return fail(SMM_ERR_ALLOC, "hipMalloc of the tile-local column array failed");
+    if (b->nnz > 0) {
+        LAUNCH(c, "smm_loc16", smm_loc16, std::min<int64_t>((b->nnz + 255) / 256, 65536), 256, 0, (int)b->nnz, g.wc, b->idx,
+               b->loc);
+        LAUNCH_CHECK();
+    }
+    b->loc_wc = g.wc;
     return SMM_OK;
 }
 
@@ -610,6 +628,7 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     if (gbm) pool_free(c, gbm);
     if (p->b_sorted && p->nnz > 0) {
         PCHK(ensure_seg(c, b, p->g));
+        PCHK(ensure_loc(c, b, p->g));
         PCHK(pool_get(c, (size_t)a->nnz * (p->g.nct + 1), &p->d_runs));
         const int rgrid = (int)std::min<int64_t>((m + 3) / 4, 65536);
         LAUNCH(c, "smm_runs", smm_runs, rgrid, 256, 0, (int)m, p->g.nct, p->g.wc, a->ptr, p->d_ub_off, p->d_rowcnt,
@@ -639,7 +658,7 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
         A.m = (int)m; A.ncols = (int)p->ncols; A.nct = p->g.nct; A.wc = p->g.wc; A.wf = p->g.wf; A.n_ft = p->g.n_ft;
         A.row_offset = p->row_offset;
         A.a_ptr = p->a->ptr; A.a_idx = p->a->idx; A.a_val = p->a->val;
-        A.b_idx = p->b->idx; A.b_val = p->b->val; A.seg = p->b->seg;
+        A.b_idx = p->b->idx; A.b_val = p->b->val; A.seg = p->b->seg; A.b_loc = p->b->loc;
         A.c_ptr = p->d_cptr; A.c_idx = d_c_indices; A.c_val = d_c_data;
         A.ub_off = p->d_ub_off; A.tmp_idx = p->d_tmp; A.runs = p->d_runs;
         CHK(launch_numeric<OUT_SPARSE>(c, A, sym, p->g.nw, (p->flags & SMM_EXACT) != 0));
@@ -714,11 +733,12 @@ static int dense_into(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t row
     if (!(b->vflags & CSR_UNSORTED)) {
         Geom g = make_geom(c, n, b, (flags & SMM_EXACT) != 0);
         CHK(ensure_seg(c, b, g));
+        CHK(ensure_loc(c, b, g));
         NumericArgs A{};
         A.m = (int)m; A.ncols = (int)n; A.nct = g.nct; A.wc = g.wc; A.wf = g.wf; A.n_ft = g.n_ft;
         A.row_offset = row_offset;
         A.a_ptr = a->ptr; A.a_idx = a->idx; A.a_val = a->val;
-        A.b_idx = b->idx; A.b_val = b->val; A.seg = b->seg;
+        A.b_idx = b->idx; A.b_val = b->val; A.seg = b->seg; A.b_loc = b->loc;
         A.c_dense = d_c; A.ldc = ldc;
         CHK(launch_numeric<OUT_DENSE>(c, A, sym, g.nw, (flags & SMM_EXACT) != 0));
     } else {
@@ -786,7 +806,7 @@ extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags,
     double *T = nullptr;
     CHK(pool_get(c, (size_t)nr * K, &T));
     smm_csr hv = *h;                       // row-range view of H (borrowed arrays)
-    hv.ptr = h->ptr + row_begin; hv.rows = nr; hv.owned = false; hv.seg = nullptr;
+    hv.ptr = h->ptr + row_begin; hv.rows = nr; hv.owned = false; hv.seg = nullptr; hv.loc = nullptr;
     // indptr of the view is not rebased: kernels only use ptr[row], ptr[row+1] as absolute positions.
     int rc = dense_into(c, &hv, q, flags & SMM_EXACT, 0, T, K);
     if (rc != SMM_OK) { pool_free(c, T); return rc; }
