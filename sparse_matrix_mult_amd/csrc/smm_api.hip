@@ -277,6 +277,9 @@ struct smm_csr {
     // cached tile index (sorted operands only)
     int *seg = nullptr; int seg_wf = 0, seg_nft = 0;
     short *loc = nullptr; int loc_wc = 0;      // tile-local columns for coarse width loc_wc
+    // sliced-ELL copy for triple-product stage 2 (chunk width ell_chunk)
+    int ell_chunk = 0, ell_nchunks = 0; int *ell_len = nullptr; int64_t *ell_off = nullptr;
+    short *ell_col = nullptr; double *ell_val = nullptr;
 };
 
 static int validate(smm_ctx *c, smm_csr *m)
@@ -360,6 +363,7 @@ extern "C" void smm_csr_destroy(smm_csr *m)
     if (m->owned) { (void)hipFree((void *)m->ptr); (void)hipFree((void *)m->idx); (void)hipFree((void *)m->val); }
     if (m->seg) (void)hipFree(m->seg);
     if (m->loc) (void)hipFree(m->loc);
+    (void)hipFree(m->ell_len); (void)hipFree(m->ell_off); (void)hipFree(m->ell_col); (void)hipFree(m->ell_val);
     delete m;
 }
 extern "C" int64_t smm_csr_rows(const smm_csr *m) { return m ? m->rows : -1; }
@@ -436,6 +440,46 @@ static int ensure_loc(smm_ctx *c, smm_csr *b, const Geom &g)
         LAUNCH_CHECK();
     }
     b->loc_wc = g.wc;
+    return SMM_OK;
+}
+
+// Sliced-ELL re-layout of H for triple-product stage 2 (see smm_triple_stage2); cached per chunk width.
+static int ensure_ell(smm_ctx *c, smm_csr *h, int nchunks, int chunk)
+{
+    if (h->ell_val && h->ell_chunk == chunk && h->ell_nchunks == nchunks) return SMM_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(h->ell_len); (void)hipFree(h->ell_off); (void)hipFree(h->ell_col); (void)hipFree(h->ell_val);
+    h->ell_len = nullptr; h->ell_off = nullptr; h->ell_col = nullptr; h->ell_val = nullptr; h->ell_chunk = 0;
+    Geom gh; gh.nw = 1; gh.nct = nchunks; gh.wf = chunk; gh.wc = chunk; gh.n_ft = nchunks;
+    CHK(ensure_seg(c, h, gh));
+    const int n = (int)h->rows;
+    const int nslices = (n + WAVE - 1) / WAVE;
+    const int64_t items = (int64_t)nchunks * nslices;
+    int64_t *cnt = nullptr;
+    CHK(pool_get(c, (size_t)items, &cnt));
+    if (hipMalloc((void **)&h->ell_len, (size_t)nchunks * n * sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&h->ell_off, (size_t)(items + 1) * sizeof(int64_t)) != hipSuccess) {
+        pool_free(c, cnt);
+        return fail(SMM_ERR_ALLOC, "hipMalloc of the ELL index failed");
+    }
+    EllArgs E{};
+    E.n = n; E.nchunks = nchunks; E.chunk = chunk; E.nslices = nslices;
+    E.h_ptr = h->ptr; E.h_idx = h->idx; E.h_val = h->val; E.hseg = h->seg;
+    E.len = h->ell_len; E.cnt = cnt; E.off = h->ell_off;
+    const int grid = (int)((items + 3) / 4);
+    LAUNCH(c, "smm_ell_count", smm_ell_count, grid, 256, 0, E);
+    LAUNCH(c, "smm_scan", smm_scan<int64_t>, 1, 1024, 0, (int)items, (const int64_t *)cnt, h->ell_off);
+    int64_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, h->ell_off + items, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    pool_free(c, cnt);
+    if (hipMalloc((void **)&h->ell_col, std::max<int64_t>(total, 1) * sizeof(short)) != hipSuccess ||
+        hipMalloc((void **)&h->ell_val, std::max<int64_t>(total, 1) * sizeof(double)) != hipSuccess)
+        return fail(SMM_ERR_ALLOC, "hipMalloc of the ELL payload (%lld entries) failed", (long long)total);
+    E.col = h->ell_col; E.val = h->ell_val;
+    LAUNCH(c, "smm_ell_fill", smm_ell_fill, grid, 256, 0, E);
+    LAUNCH_CHECK();
+    h->ell_chunk = chunk; h->ell_nchunks = nchunks;
     return SMM_OK;
 }
 
@@ -811,18 +855,16 @@ extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags,
     int rc = dense_into(c, &hv, q, flags & SMM_EXACT, 0, T, K);
     if (rc != SMM_OK) { pool_free(c, T); return rc; }
     // stage 2
-    constexpr int R = 4, NW = 8;
+    constexpr int R = 8, NW = 16;
     const int chunk_cap = 16384 / R;       // 128 KB of LDS for R tile rows
     const int nchunks = (int)((K + chunk_cap - 1) / chunk_cap);
     const int chunk = (int)((K + nchunks - 1) / nchunks);
-    // H's tile index with tile width = chunk
-    Geom gh; gh.nw = 1; gh.nct = nchunks; gh.wf = chunk; gh.wc = chunk; gh.n_ft = nchunks;
-    rc = ensure_seg(c, h, gh);
+    rc = ensure_ell(c, h, nchunks, chunk);
     if (rc != SMM_OK) { pool_free(c, T); return rc; }
     TripleArgs A{};
-    A.n = (int)n; A.K = (int)K; A.nchunks = nchunks; A.chunk = chunk;
+    A.n = (int)n; A.K = (int)K; A.nchunks = nchunks; A.chunk = chunk; A.nslices = (int)((n + WAVE - 1) / WAVE);
     A.row_begin = row_begin; A.row_end = row_end; A.full = full ? 1 : 0;
-    A.h_ptr = h->ptr; A.h_idx = h->idx; A.h_val = h->val; A.hseg = h->seg;
+    A.len = h->ell_len; A.off = h->ell_off; A.col = h->ell_col; A.val = h->ell_val;
     A.T = T; A.C = d_c; A.ldc = n;
     const size_t lds = (size_t)R * chunk * sizeof(double);
     auto kern = smm_triple_stage2<R, NW>;

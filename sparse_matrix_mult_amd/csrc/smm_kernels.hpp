@@ -788,18 +788,78 @@ __global__ __launch_bounds__(256) void smm_dense_general(int m, int ncols, int64
 // ---------------------------------------------------------------------------------------
 // Triple product, stage 2 (sparse_sparse_dense.cpp:201-216): C[i,k] = sum over row k of H of
 // T[i, col] * val, for k >= i (or all k), where T = H*Q is the dense n x K matrix stage 1
-// (smm_numeric<OUT_DENSE>) left in HBM.  The sum runs in H's stored order starting from
-// 0.0, exactly as the reference's scalar loop.
-// Workgroup = R rows i of T x one chunk of K columns in LDS; the running sums of a row live
-// in C itself between chunks (chunks are visited in ascending column order = stored order
-// of a sorted H, so the order of additions is unchanged).  Each lane owns one k and walks
-// its H segment; hseg is H's tile index with tile width = chunk.
-struct TripleArgs {
-    int n, K, nchunks, chunk;
-    int64_t row_begin, row_end;
-    int full;
+// (smm_numeric<OUT_DENSE>) left in HBM.  The sum runs in H's stored order starting from 0.0,
+// exactly as the reference's scalar loop, so stage 2 is bit-exact given T.
+//
+// Layout.  K is cut into chunks of `chunk` columns; a workgroup holds R rows of T for one chunk
+// in LDS ([R][chunk] f64 = 128 KB) and every lane owns one k: it walks the part of H's row k
+// that falls into the chunk and feeds R running sums.  Between chunks the running sums of a
+// row live in C itself; chunks are visited in ascending column order = stored order of a
+// sorted H, so the order of additions is the reference's.
+// A lane walking its own CSR row would make every load 64 separate 12-byte requests, so H is
+// re-laid once (cached on the handle) as sliced ELL per chunk: for 64 consecutive rows k and
+// chunk q, step s of all 64 rows is stored contiguously -- int16 chunk-local column + f64
+// value -- padded to the longest of the 64 segments (rows of H are ~equal length: ~10-15 %).
+struct EllArgs {
+    int n, nchunks, chunk, nslices;
     const int *h_ptr, *h_idx; const double *h_val;
     const int *hseg;                  // [n][nchunks+1]
+    int *len;                         // [nchunks][n]        segment length of row k in chunk q
+    int64_t *cnt;                     // [nchunks][nslices]  64 * longest segment of the slice
+    const int64_t *off;               // exclusive scan of cnt (+ total)
+    short *col; double *val;          // ELL payload
+};
+
+// pass 1: lengths and per-slice maxima (one wave per (chunk, slice))
+__global__ __launch_bounds__(256) void smm_ell_count(const EllArgs A)
+{
+    const int lane = lane_id();
+    const int64_t item = (int64_t)blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x >> 6);
+    if (item >= (int64_t)A.nchunks * A.nslices) return;
+    const int q = (int)(item / A.nslices), sl = (int)(item % A.nslices);
+    const int k = sl * WAVE + lane;
+    int len = 0;
+    if (k < A.n) {
+        const int *sp = A.hseg + (size_t)k * (A.nchunks + 1) + q;
+        len = sp[1] - sp[0];
+        A.len[(size_t)q * A.n + k] = len;
+    }
+    int mx = len;
+    for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
+    if (lane == 0) A.cnt[item] = (int64_t)mx * WAVE;
+}
+
+// pass 2: payload (one wave per (chunk, slice))
+__global__ __launch_bounds__(256) void smm_ell_fill(const EllArgs A)
+{
+    const int lane = lane_id();
+    const int64_t item = (int64_t)blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x >> 6);
+    if (item >= (int64_t)A.nchunks * A.nslices) return;
+    const int q = (int)(item / A.nslices), sl = (int)(item % A.nslices);
+    const int k = sl * WAVE + lane;
+    int s = 0, len = 0;
+    if (k < A.n) {
+        const int *sp = A.hseg + (size_t)k * (A.nchunks + 1) + q;
+        s = sp[0]; len = sp[1] - sp[0];
+    }
+    const int64_t base = A.off[item];
+    const int steps = (int)((A.off[item + 1] - base) / WAVE);
+    const int lo = q * A.chunk;
+    for (int st = 0; st < steps; ++st) {
+        short c = 0; double v = 0.0;
+        if (st < len) { c = (short)(A.h_idx[s + st] - lo); v = A.h_val[s + st]; }
+        A.col[base + (int64_t)st * WAVE + lane] = c;
+        A.val[base + (int64_t)st * WAVE + lane] = v;
+    }
+}
+
+struct TripleArgs {
+    int n, K, nchunks, chunk, nslices;
+    int64_t row_begin, row_end;
+    int full;
+    const int *len;                   // [nchunks][n]
+    const int64_t *off;               // [nchunks*nslices + 1]
+    const short *col; const double *val;
     const double *T;                  // (row_end-row_begin) x K
     double *C; int64_t ldc;           // row row_begin at C
 };
@@ -808,38 +868,48 @@ template <int R, int NW>
 __global__ __launch_bounds__(NW * 64) void smm_triple_stage2(const TripleArgs A)
 {
     extern __shared__ double tl[];                     // [R][chunk]
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t i0 = A.row_begin + (int64_t)blockIdx.x * R;
     const int nr = (A.row_end - i0) < R ? (int)(A.row_end - i0) : R;
-    const int per = A.nchunks + 1;
-    const int64_t kfirst = A.full ? 0 : i0;            // lanes below their own row's diagonal are masked
+    const int first_slice = A.full ? 0 : (int)(i0 / WAVE);     // slices left of the diagonal hold nothing
     for (int q = 0; q < A.nchunks; ++q) {
         const int lo = q * A.chunk;
         const int w = (A.K - lo) < A.chunk ? (A.K - lo) : A.chunk;
         __syncthreads();
-        for (int r = 0; r < nr; ++r) {
-            const double *src = A.T + (int64_t)(i0 - A.row_begin + r) * A.K + lo;
+        for (int r = 0; r < R; ++r) {
+            const double *src = A.T + (int64_t)(i0 - A.row_begin + (r < nr ? r : nr - 1)) * A.K + lo;
             for (int x = threadIdx.x; x < w; x += NW * 64) tl[r * A.chunk + x] = src[x];
         }
         __syncthreads();
-        for (int64_t k = kfirst + threadIdx.x; k < A.n; k += NW * 64) {
-            const int s = A.hseg[k * per + q], e = A.hseg[k * per + q + 1];
+        for (int sl = first_slice + wave; sl < A.nslices; sl += NW) {
+            const int64_t k = (int64_t)sl * WAVE + lane;
+            const bool kin = k < A.n;
+            const int len = kin ? A.len[(size_t)q * A.n + k] : 0;
+            const int64_t base = A.off[(size_t)q * A.nslices + sl];
+            const int steps = (int)((A.off[(size_t)q * A.nslices + sl + 1] - base) / WAVE);
             double sum[R];
+            bool mine[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
+                mine[r] = kin && r < nr && (A.full || k >= i0 + r);
                 sum[r] = 0.0;
-                if (q > 0 && r < nr && (A.full || k >= i0 + r))
-                    sum[r] = A.C[(int64_t)(i0 - A.row_begin + r) * A.ldc + k];
+                if (q > 0 && mine[r]) sum[r] = A.C[(int64_t)(i0 - A.row_begin + r) * A.ldc + k];
             }
-            for (int jp = s; jp < e; ++jp) {
-                const int col = A.h_idx[jp] - lo;
-                const double hv = A.h_val[jp];
+            const short *cp = A.col + base + lane;
+            const double *vp = A.val + base + lane;
+#pragma unroll 4
+            for (int st = 0; st < steps; ++st) {
+                const int c = cp[(int64_t)st * WAVE];
+                const double hv = vp[(int64_t)st * WAVE];
+                if (st < len) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) sum[r] += tl[r * A.chunk + col] * hv;
+                    for (int r = 0; r < R; ++r) sum[r] += tl[r * A.chunk + c] * hv;
+                }
             }
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                if (r < nr && (A.full || k >= i0 + r))
-                    A.C[(int64_t)(i0 - A.row_begin + r) * A.ldc + k] = sum[r];
+                if (mine[r]) A.C[(int64_t)(i0 - A.row_begin + r) * A.ldc + k] = sum[r];
         }
     }
     // cells left of the diagonal: the reference's calloc'd zeros
