@@ -59,9 +59,11 @@ def gen_csr_device(torch, rows, cols, density, seed, device):
     return indptr.to(torch.int32), indices, data
 
 
-def cpu_baseline(torch, a, b, cols, target_s=12.0):
+def cpu_baseline(torch, a, b, cols, gpu_result=None, target_s=12.0):
     """Time the oracle (kind 'port': our C restatement of src/sparsework.cpp) on the first R
-    rows of A against all of B, single thread, on this box's host."""
+    rows of A against all of B, single thread, on this box's host.  When the GPU result of the
+    last step is passed in, the same rows are compared with it (full-size parity check:
+    indptr / indices bit-exact, values within 1e-10 relative)."""
     from oracle import oracle
     ap, ai, av = (t.cpu().numpy() for t in a)
     bp, bi, bv = (t.cpu().numpy() for t in b)
@@ -72,10 +74,20 @@ def cpu_baseline(torch, a, b, cols, target_s=12.0):
     dt = max(time.perf_counter() - t0, 1e-6)
     sample = int(max(probe, min(rows, probe * target_s / dt)))
     t0 = time.perf_counter()
-    cnt, _, _ = oracle.sparse_rows((ap, ai, av), (bp, bi, bv), cols, 0, sample)
+    cnt, idx, val = oracle.sparse_rows((ap, ai, av), (bp, bi, bv), cols, 0, sample)
     dt = time.perf_counter() - t0
-    return {"value": float(cnt.sum() / dt), "unit": "nnz/s", "cores": 1, "kind": "port",
-            "sample": f"first {sample} of {rows} rows of A x all of B, {int(cnt.sum())} output nnz in {dt:.2f} s"}
+    out = {"value": float(cnt.sum() / dt), "unit": "nnz/s", "cores": 1, "kind": "port",
+           "sample": f"first {sample} of {rows} rows of A x all of B, {int(cnt.sum())} output nnz in {dt:.2f} s"}
+    if gpu_result is not None:
+        g_ptr, g_idx, g_val = gpu_result
+        nn = int(cnt.sum())
+        ok_ptr = np.array_equal(g_ptr[:sample + 1].cpu().numpy(), np.concatenate([[0], np.cumsum(cnt)]))
+        ok_idx = np.array_equal(g_idx[:nn].cpu().numpy(), idx)
+        gv = g_val[:nn].cpu().numpy()
+        rel = float(np.max(np.abs(gv - val) / np.maximum(np.abs(val), 1e-300))) if nn else 0.0
+        out["parity_on_sample"] = {"indptr_bit_exact": bool(ok_ptr), "indices_bit_exact": bool(ok_idx),
+                                   "values_max_rel_err": rel, "values_bit_exact": bool(np.array_equal(gv, val))}
+    return out
 
 
 def main():
@@ -147,10 +159,11 @@ def main():
     ctx.timing_reset()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for it in range(args.steps):
         out = step()
         nnz_c = int(out[1].numel())
-        del out
+        if it + 1 < args.steps or args.no_cpu or rank != 0:
+            del out                               # rank 0 keeps the last result for the parity check
     fence()
     elapsed = time.perf_counter() - t0
     num_ms, num_n = ctx.kernel_time("smm_numeric")
@@ -201,7 +214,8 @@ def main():
                          "symbolic_kernel_ms": sym_ms / max(sym_n, 1)},
         }
         if not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(torch, a_t, b_t, n)
+            local_ptr = out[0] if world == 1 else out[0][:m + 1]      # rank 0's block comes first
+            line["cpu_baseline"] = cpu_baseline(torch, a_t, b_t, n, (local_ptr, out[1], out[2]))
         print(json.dumps(line), flush=True)
 
     A.close(); B.close(); ctx.close()
