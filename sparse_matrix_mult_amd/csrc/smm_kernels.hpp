@@ -525,7 +525,10 @@ row_done:
 // given up is the ORDER in which one accumulator receives its products, so values agree with
 // the reference to rounding (a few ulp; tests hold them to the north star's 1e-10) instead
 // of bit for bit.  SMM_EXACT selects smm_accumulate above instead.
-constexpr int CH_UNROLL = 8;
+#ifndef SMM_CH_UNROLL
+#define SMM_CH_UNROLL 8
+#endif
+constexpr int CH_UNROLL = SMM_CH_UNROLL;
 
 template <bool SYM, int NW>
 __device__ __forceinline__ void smm_accumulate_shared(const NumericArgs &A, double *__restrict__ acc, const int lo_c,
@@ -600,7 +603,10 @@ __device__ __forceinline__ void smm_accumulate_shared(const NumericArgs &A, doub
     }
 }
 
-constexpr int EPI_UNROLL = 4;
+#ifndef SMM_EPI_UNROLL
+#define SMM_EPI_UNROLL 4
+#endif
+constexpr int EPI_UNROLL = SMM_EPI_UNROLL;
 
 template <int OUT, bool SYM, int NW, bool EXACT>
 __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)

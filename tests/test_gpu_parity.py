@@ -223,6 +223,34 @@ def test_row_shards_concatenate_to_single_result(ctx, oracle):
         assert_csr_equal(got, want, values="bits")
 
 
+def test_very_wide_b_uses_the_global_bitmap(ctx, oracle):
+    """More than 262 144 columns: the first-touch marker no longer fits LDS and lives in HBM
+    (smm_symbolic<LDSBM=false>); many coarse tiles, mostly empty segments."""
+    n = 300_000
+    A, B = rand_csr(40, 200, 0.2, 41), rand_csr(200, n, 0.0005, 42)
+    for symmetric in (False,):
+        want = oracle.sparse(arrays(A), arrays(B), n, symmetric=symmetric)
+        a, b = ctx.csr_from_scipy(A), ctx.csr_from_scipy(B)
+        try:
+            assert_csr_equal(ctx.spgemm_host(a, b, exact=True), want, values="bits")
+            assert_csr_equal(ctx.spgemm_host(a, b), want, values="tol", rtol=RTOL)
+        finally:
+            a.close(); b.close()
+
+
+def test_unsorted_b_symmetric_and_dense_general_paths(ctx, oracle):
+    A, B = rand_csr(100, 90, 0.1, 43), shuffle_rows(rand_csr(90, 100, 0.1, 44), 45)
+    a, b = ctx.csr_from_scipy(A), ctx.csr_from_scipy(B)
+    try:
+        for symmetric in (False, True):
+            want = oracle.sparse(arrays(A), arrays(B), 100, symmetric=symmetric)
+            assert_csr_equal(ctx.spgemm_host(a, b, symmetric=symmetric), want, values="tol", rtol=RTOL)
+            wd = oracle.dense(arrays(A), arrays(B), 100, symmetric=symmetric)
+            assert rel_err(ctx.dense_host(a, b, symmetric=symmetric), wd) <= RTOL
+    finally:
+        a.close(); b.close()
+
+
 def test_malformed_operand_is_rejected(ctx):
     from sparse_matrix_mult_amd.engine import SmmError
     indptr = np.array([0, 2, 3], dtype=np.int32)
