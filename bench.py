@@ -61,23 +61,39 @@ def gen_csr_device(torch, rows, cols, density, seed, device):
 
 def cpu_baseline(torch, a, b, cols, gpu_result=None, target_s=12.0):
     """Time the oracle (kind 'port': our C restatement of src/sparsework.cpp) on the first R
-    rows of A against all of B, single thread, on this box's host.  When the GPU result of the
+    rows of A against all of B on this box's host cores (one thread per core, disjoint row
+    ranges -- the reference's own row-block parallelism, sparse_sparse_sparse.cpp:228-249).  When the GPU result of the
     last step is passed in, the same rows are compared with it (full-size parity check:
     indptr / indices bit-exact, values within 1e-10 relative)."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle
     ap, ai, av = (t.cpu().numpy() for t in a)
     bp, bi, bv = (t.cpu().numpy() for t in b)
+    A_, B_ = (ap, ai, av), (bp, bi, bv)
     rows = len(ap) - 1
-    probe = max(1, min(rows, 64))
+    # host threads actually used: one per core this process may run on (rows are independent;
+    # ctypes releases the GIL, every call has its own marker array)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64, rows))
+    probe = max(1, min(rows, 32))
     t0 = time.perf_counter()
-    oracle.sparse_rows((ap, ai, av), (bp, bi, bv), cols, 0, probe)
-    dt = max(time.perf_counter() - t0, 1e-6)
-    sample = int(max(probe, min(rows, probe * target_s / dt)))
-    t0 = time.perf_counter()
-    cnt, idx, val = oracle.sparse_rows((ap, ai, av), (bp, bi, bv), cols, 0, sample)
-    dt = time.perf_counter() - t0
-    out = {"value": float(cnt.sum() / dt), "unit": "nnz/s", "cores": 1, "kind": "port",
-           "sample": f"first {sample} of {rows} rows of A x all of B, {int(cnt.sum())} output nnz in {dt:.2f} s"}
+    oracle.sparse_rows(A_, B_, cols, 0, probe)
+    dt1 = max(time.perf_counter() - t0, 1e-6)
+    # ~10-30 core-seconds of work, at most 20 000 rows (the sample's CSR is held on the host)
+    sample = int(max(cores, min(rows, 20000, probe * target_s / dt1 * cores * 0.6)))
+    bounds = [sample * i // cores for i in range(cores + 1)]
+    with ThreadPoolExecutor(cores) as pool:
+        t0 = time.perf_counter()
+        parts = list(pool.map(lambda i: oracle.sparse_rows(A_, B_, cols, bounds[i], bounds[i + 1]), range(cores)))
+        dt = time.perf_counter() - t0
+    cnt = np.concatenate([p[0] for p in parts]); idx = np.concatenate([p[1] for p in parts])
+    val = np.concatenate([p[2] for p in parts])
+    out = {"value": float(cnt.sum() / dt), "unit": "nnz/s", "cores": cores, "kind": "port",
+           "sample": f"first {sample} of {rows} rows of A x all of B on {cores} host threads, "
+                     f"{int(cnt.sum())} output nnz in {dt:.2f} s (one thread alone: {probe / dt1 * cnt.sum() / sample:.3g} nnz/s)"}
     if gpu_result is not None:
         g_ptr, g_idx, g_val = gpu_result
         nn = int(cnt.sum())
@@ -112,13 +128,21 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         args.gpus = world
+    # SMM_BENCH_REHEARSAL=1: every rank on GPU 0 with gloo collectives -- a way to rehearse the
+    # N > 1 code path on a one-GPU box (RCCL refuses two ranks on one device).  Never a result.
+    rehearsal = os.environ.get("SMM_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from sparse_matrix_mult_amd.engine import Context
     from sparse_matrix_mult_amd import distributed as smm_dist
@@ -143,7 +167,7 @@ def main():
         plan.numeric_into(indptr.data_ptr(), indices.data_ptr(), data.data_ptr())
         plan.close()
         if world > 1:
-            indptr = smm_dist.global_indptr(indptr, dist)               # the exchange step
+            indptr = smm_dist.global_indptr(indptr, dist, equal_rows=True)   # the exchange step
         return indptr, indices, data
 
     def fence():
@@ -170,7 +194,7 @@ def main():
     sym_ms, sym_n = ctx.kernel_time("smm_symbolic")
     ctx.timing(False)
 
-    t = torch.tensor([elapsed, float(nnz_c)], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed, float(nnz_c)], dtype=torch.float64, device="cpu" if rehearsal else device)
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

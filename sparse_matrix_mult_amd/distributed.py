@@ -49,12 +49,26 @@ def _world(dist, group=None):
     return dist.get_world_size(group), dist.get_rank(group)
 
 
+def _stage(t, dist, group):
+    """gloo moves host memory only: stage device tensors through the host there (rehearsals and
+    the CPU tests); RCCL takes device tensors as they are."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        return t.cpu(), t.device
+    return t, None
+
+
 def allgatherv(local, dist, group=None):
     """Variable-length all-gather of a 1-D tensor: returns (concatenation in rank order,
     per-rank lengths).  Sizes are exchanged first (one tiny all_gather), then every rank
     sends its shard to every peer and receives theirs in ONE batch of point-to-point ops."""
     import torch
     world, rank = _world(dist, group)
+    local, back = _stage(local.contiguous(), dist, group)
+    out, sizes = _allgatherv(local, dist, group, world, rank, torch)
+    return (out.to(back) if back is not None else out), sizes
+
+
+def _allgatherv(local, dist, group, world, rank, torch):
     n_local = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
     sizes = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(sizes, n_local, group=group)
@@ -83,12 +97,21 @@ def _global_rank(dist, group, group_rank):
     return dist.get_global_rank(group, group_rank)
 
 
-def global_indptr(local_indptr, dist, group=None):
+def global_indptr(local_indptr, dist, group=None, equal_rows=False):
     """local_indptr: int64, rows_local+1, starting at 0.  Returns the global row pointer
-    (sum(rows)+1 entries) of the row-concatenated result on every rank."""
+    (sum(rows)+1 entries) of the row-concatenated result on every rank.  equal_rows=True (every
+    rank holds the same number of rows, as in bench.py) uses one plain all_gather."""
     import torch
-    counts = local_indptr[1:] - local_indptr[:-1]
-    all_counts, _ = allgatherv(counts.contiguous(), dist, group)
+    counts = (local_indptr[1:] - local_indptr[:-1]).contiguous()
+    if equal_rows:
+        world, _ = _world(dist, group)
+        send, back = _stage(counts, dist, group)
+        all_counts = torch.empty(world * send.numel(), dtype=send.dtype, device=send.device)
+        dist.all_gather_into_tensor(all_counts, send, group=group)
+        if back is not None:
+            all_counts = all_counts.to(back)
+    else:
+        all_counts, _ = allgatherv(counts, dist, group)
     out = torch.zeros(all_counts.numel() + 1, dtype=torch.int64, device=local_indptr.device)
     torch.cumsum(all_counts, 0, out=out[1:])
     return out

@@ -42,6 +42,11 @@ def _worker(rank, world, port, symmetric, ret):
         g_ptr, g_idx, g_val = allgather_csr(indptr, torch.from_numpy(idx), torch.from_numpy(val), dist)
         g_only = global_indptr(indptr, dist)
         want = oracle.sparse(a, b, 203, symmetric=symmetric)
+        # equal-row form used by bench.py: one plain all_gather of the counts
+        loc = torch.from_numpy(np.concatenate([[0], np.cumsum(np.arange(1, 8) * (rank + 1))]).astype(np.int64))
+        eq = global_indptr(loc, dist, equal_rows=True).numpy()
+        eq_want = np.concatenate([[0], np.cumsum(np.concatenate([np.arange(1, 8) * (r + 1) for r in range(world)]))])
+        assert np.array_equal(eq, eq_want)
         ok = (np.array_equal(g_ptr.numpy(), want[0]) and np.array_equal(g_idx.numpy(), want[1])
               and np.array_equal(g_val.numpy(), want[2]) and np.array_equal(g_only.numpy(), want[0]))
         ret[rank] = bool(ok)
