@@ -77,7 +77,7 @@ def cpu_baseline(torch, a, b, cols, gpu_result=None, target_s=12.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64, rows))
+    cores = max(1, min(cores, 16, rows))          # the GPU box's CPU share for one GPU is 16
     probe = max(1, min(rows, 32))
     t0 = time.perf_counter()
     oracle.sparse_rows(A_, B_, cols, 0, probe)

@@ -591,13 +591,13 @@ extern "C" void smm_plan_destroy(smm_plan *p)
 extern "C" int64_t smm_plan_nnz(const smm_plan *p) { return p ? p->nnz : -1; }
 
 template <bool SYM, bool SAFE, bool LDSBM>
-static int launch_symbolic_t(smm_ctx *c, smm_plan *p, int bm_words, unsigned *gbm, int grid)
+static int launch_symbolic_t(smm_ctx *c, smm_plan *p, int bm_words, unsigned *gbm, int grid, int wpb)
 {
-    const size_t lds = LDSBM ? (size_t)bm_words * 4 * sizeof(unsigned) : 0;
+    const size_t lds = LDSBM ? (size_t)bm_words * wpb * sizeof(unsigned) : 0;
     auto kern = smm_symbolic<SYM, SAFE, LDSBM>;
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    LAUNCH(c, "smm_symbolic", kern, grid, 256, lds, (int)p->m, p->row_offset, bm_words, p->a->ptr, p->a->idx,
+    LAUNCH(c, "smm_symbolic", kern, grid, wpb * 64, lds, (int)p->m, p->row_offset, bm_words, p->a->ptr, p->a->idx,
            p->b->ptr, p->b->idx, p->d_ub_off, p->d_tmp, p->d_P, p->d_rowcnt, gbm,
            (const int *)((const char *)c->d_flags + 64));
     LAUNCH_CHECK();
@@ -651,14 +651,24 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     PCHK(pool_get(c, (size_t)a->nnz, &p->d_P));
     PCHK(pool_get(c, (size_t)m, &p->d_rowcnt));
 
-    // symbolic: one wave per row, 4 rows per workgroup
+    // symbolic: one wave per row.  The marker bitmap (ncols/8 bytes per wave) lives in LDS; waves per
+    // workgroup are chosen so that as many waves as possible fit a CU's 160 KB
     const int bm_words = (int)((p->ncols + 31) / 32);
-    const bool ldsbm = (size_t)bm_words * 4 * sizeof(unsigned) <= 128 * 1024;
+    const size_t bm_bytes = (size_t)bm_words * sizeof(unsigned);
+    const bool ldsbm = bm_bytes <= 128 * 1024;
     const bool safe = (b->vflags & (CSR_HAS_EQUAL | CSR_UNSORTED)) != 0;
-    int sgrid = (int)std::min<int64_t>((m + 3) / 4, (int64_t)c->n_cu * 8);
+    int wpb = 4;
+    if (ldsbm) {
+        int best = 0;
+        for (int cand : {4, 2, 1}) {
+            const int waves = (int)std::min<size_t>(32, ((size_t)160 * 1024 / (cand * bm_bytes)) * cand);
+            if (waves > best) { best = waves; wpb = cand; }
+        }
+    }
+    int sgrid = (int)std::min<int64_t>((m + wpb - 1) / wpb, (int64_t)c->n_cu * 8 * (4 / wpb));
     unsigned *gbm = nullptr;
-    if (!ldsbm) PCHK(pool_get(c, (size_t)sgrid * 4 * bm_words, &gbm));
-#define SYM_CASE(S, F, L) if (sym == S && safe == F && ldsbm == L) PCHK((launch_symbolic_t<S, F, L>(c, p, bm_words, gbm, sgrid)));
+    if (!ldsbm) PCHK(pool_get(c, (size_t)sgrid * wpb * bm_words, &gbm));
+#define SYM_CASE(S, F, L) if (sym == S && safe == F && ldsbm == L) PCHK((launch_symbolic_t<S, F, L>(c, p, bm_words, gbm, sgrid, wpb)));
     SYM_CASE(false, false, true) SYM_CASE(false, true, true) SYM_CASE(true, false, true) SYM_CASE(true, true, true)
     SYM_CASE(false, false, false) SYM_CASE(false, true, false) SYM_CASE(true, false, false) SYM_CASE(true, true, false)
 #undef SYM_CASE
