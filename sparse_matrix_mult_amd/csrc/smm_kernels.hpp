@@ -262,20 +262,27 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, i
                         kb += WAVE;
                         if (live && kb >= en) advance();
                     }
+                    // test-and-set every chunk's columns (LDS atomics of one wave execute in issue
+                    // order, so chunk u sees the bits of chunks < u whenever its result is read);
+                    // idle lanes OR a zero into word 0.  All 16 atomics are issued before the first
+                    // result is consumed: one LDS round trip per round instead of one per chunk.
+                    unsigned old[SYM_UNROLL], bit[SYM_UNROLL], pre[SYM_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < SYM_UNROLL; ++u) {
+                        const bool a = c[u] >= thresh;                  // also drops the dummy -1
+                        bit[u] = a ? 1u << (c[u] & 31) : 0u;
+                        unsigned *wp = bm + (a ? (c[u] >> 5) : 0);
+                        if (SAFE) pre[u] = *(volatile unsigned *)wp;
+                        old[u] = atomicOr(wp, bit[u]);
+                    }
 #pragma unroll
                     for (int u = 0; u < SYM_UNROLL; ++u) {              // then consume in order
                         if (lane == owner[u]) myP = (unsigned)n;
-                        const bool a = c[u] >= thresh;                  // also drops the dummy -1
-                        const unsigned bit = 1u << (c[u] & 31);
-                        unsigned *wp = bm + (a ? (c[u] >> 5) : 0);
-                        bool isnew = false;
+                        bool isnew = (bit[u] & ~old[u]) != 0;
                         if (SAFE) {
-                            bool pre = true;
-                            if (a) pre = (*(volatile unsigned *)wp & bit) != 0;
-                            bool hw = false;
-                            if (a) hw = (atomicOr(wp, bit) & bit) == 0;
-                            isnew = hw;
-                            unsigned long long losers = __ballot(a && !pre && !hw);
+                            // two lanes of this instruction with the same new column: the LOWEST wins
+                            const bool a = bit[u] != 0;
+                            unsigned long long losers = __ballot(a && !(pre[u] & bit[u]) && !isnew);
                             while (losers) {                     // rare: duplicate column in a B row
                                 const int x = __ffsll((long long)losers) - 1;
                                 const int cx = rl(c[u], x);
@@ -285,8 +292,6 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, i
                                 if (ingrp) isnew = (lane == firstl);
                                 losers &= ~grp;
                             }
-                        } else {
-                            if (a) isnew = (atomicOr(wp, bit) & bit) == 0;
                         }
                         const unsigned long long mask = __ballot(isnew);
                         if (isnew) out[n + mbcnt(mask)] = c[u];
