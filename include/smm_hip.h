@@ -51,7 +51,11 @@ typedef struct smm_ctx  smm_ctx;   /* one device + one stream + a workspace aren
 typedef struct smm_csr  smm_csr;   /* a CSR operand resident in HBM (+ cached tile index) */
 typedef struct smm_plan smm_plan;  /* result of the symbolic phase of one product         */
 
-/* ------------------------------------------------------------------ context */
+/* ------------------------------------------------------------------ context
+ * A context owns one device, one stream and a workspace pool.  It is NOT thread-safe: use one
+ * context per host thread (the legacy symbols below share one context and serialise on it).
+ * Handles (smm_csr, smm_plan) belong to the context that made them; a plan borrows its two
+ * operands, which must stay alive until the plan is destroyed. */
 int         smm_device_count(void);              /* number of usable devices, 0 if none  */
 const char *smm_last_error(void);                /* thread-local message of the last failure */
 /* hip_stream: a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream),

@@ -15,7 +15,8 @@
 #include <vector>
 
 static smm_ctx *g_ctx = nullptr;
-static std::mutex g_mu;
+static std::mutex g_mu;          // guards creation of the shared context
+static std::mutex g_call_mu;     // a context is single-threaded: legacy calls are serialised on it
 
 static smm_ctx *legacy_ctx()
 {
@@ -148,6 +149,7 @@ void sparse_impl(const struct sparsemat *a, const struct sparsemat *b, struct sp
     if (nr <= 0 || a->nzmax == 0 || b->nzmax == 0) return;     // sparse_sparse_sparse.cpp:181-185
     smm_ctx *c = legacy_ctx();
     if (!c) return;
+    std::lock_guard<std::mutex> call_lock(g_call_mu);
     Operand A, B;
     if (!upload(c, a, A, row0, row1) || !upload(c, b, B)) return;
     smm_plan *plan = nullptr;
@@ -194,6 +196,7 @@ void dense_impl(const struct sparsemat *a, const struct sparsemat *b, struct dar
     if (total == 0 || a->nzmax == 0 || b->nzmax == 0) return;
     smm_ctx *c = legacy_ctx();
     if (!c) { free(out->array); out->array = nullptr; return; }
+    std::lock_guard<std::mutex> call_lock(g_call_mu);
     Operand A, B;
     if (!upload(c, a, A) || !upload(c, b, B) ||
         smm_spgemm_dense_host(c, A.h, B.h, flags, 0, out->array) != SMM_OK) {
@@ -251,6 +254,7 @@ void triple_product(struct sparsemat *h, struct sparsemat *q, struct darray *out
     if (total == 0 || h->nzmax == 0 || q->nzmax == 0) return;
     smm_ctx *c = legacy_ctx();
     if (!c) { free(out->array); out->array = nullptr; return; }
+    std::lock_guard<std::mutex> call_lock(g_call_mu);
     Operand H, Q;
     if (!upload(c, h, H) || !upload(c, q, Q) ||
         smm_triple_product_host(c, H.h, Q.h, compute_full_matrix ? SMM_FULL_MATRIX : 0, 0, n, out->array) != SMM_OK) {
