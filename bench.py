@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--exact", action="store_true", help="SMM_EXACT: reference-order accumulation (bit-exact values)")
     ap.add_argument("--lds-cols", type=int, default=0)
     ap.add_argument("--waves", type=int, default=0)
+    ap.add_argument("--hash", type=str, default="", help="small,medium thresholds of the LDS-hash kernels (0,0 = off)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -151,6 +152,9 @@ def main():
     ctx = Context(local, stream)
     if args.lds_cols or args.waves:
         (ctx.tune if args.exact else ctx.tune_shared)(args.lds_cols, args.waves)
+
+    if args.hash:
+        ctx.tune_hash(*[int(x) for x in args.hash.split(",")])
 
     m, n, d = args.rows, args.cols, args.density
     a_t = gen_csr_device(torch, m, n, d, 1 + 1000 * rank, device)      # rank's row block of A

@@ -75,6 +75,10 @@ int  smm_ctx_kernel_time(smm_ctx *ctx, const char *kernel, double *ms_total, int
  * In SMM_EXACT mode results do not depend on them, bit for bit. */
 int  smm_ctx_tune(smm_ctx *ctx, int lds_cols, int waves);             /* SMM_EXACT walk          */
 int  smm_ctx_tune_shared(smm_ctx *ctx, int lds_cols, int waves);      /* default walk (4/8/16)   */
+/* Rows of C with at most small_max (<= 256) / medium_max (<= 2048) nonzeros are accumulated in an
+ * LDS hash table (one wave / one workgroup per row) instead of dense LDS tiles; 0, 0 turns the
+ * hash kernels off.  Defaults 256 / 2048. */
+int  smm_ctx_tune_hash(smm_ctx *ctx, int small_max, int medium_max);
 
 /* ------------------------------------------------------------------ operands
  * Replaces create_sparsemat + the three memmoves of csr_to_sparsemat

@@ -61,6 +61,8 @@ struct smm_ctx {
     int waves = 8;           // ... and waves per workgroup (each owns lds_cols/waves columns)
     int lds_cols_shared = 20000;   // default (shared-tile) walk: tile columns and waves per workgroup
     int waves_shared = 16;
+    int hash_small = 256;    // rows of C with <= hash_small nonzeros: one wave per row, LDS hash (0 = off)
+    int hash_medium = 2048;  // ... <= hash_medium: one workgroup per row, LDS hash; above: dense LDS tiles
     int seg_target = 40;     // aimed-at entries of B per (row of B, fine tile) segment; <= 64 lanes
     int n_cu = 256;
     std::vector<PoolBlock> pool;          // free blocks
@@ -249,6 +251,15 @@ extern "C" int smm_ctx_tune(smm_ctx *c, int lds_cols, int waves)
         if (waves != 1 && waves != 2 && waves != 4 && waves != 8) return fail(SMM_ERR_INVALID, "waves must be 1, 2, 4 or 8");
         c->waves = waves;
     }
+    return SMM_OK;
+}
+extern "C" int smm_ctx_tune_hash(smm_ctx *c, int small_max, int medium_max)
+{
+    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    if (small_max < 0 || small_max > 256 || medium_max < 0 || medium_max > 2048)
+        return fail(SMM_ERR_INVALID, "hash thresholds must be in [0,256] and [0,2048]");
+    c->hash_small = small_max;
+    c->hash_medium = std::max(medium_max, small_max);
     return SMM_OK;
 }
 extern "C" int smm_ctx_tune_shared(smm_ctx *c, int lds_cols, int waves)
@@ -575,6 +586,8 @@ struct smm_plan {
     unsigned *d_P = nullptr;       // nnz(A)
     unsigned *d_runs = nullptr;    // nnz(A) x (nct+1)
     int *d_rowcnt = nullptr;       // m
+    int *d_lists = nullptr;        // 3 x m: rows of the small / medium / dense bins
+    int n_bin[3] = {0, 0, 0};
     int64_t *d_cptr = nullptr;     // m+1
 };
 
@@ -585,7 +598,7 @@ extern "C" void smm_plan_destroy(smm_plan *p)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     pool_free(c, p->d_ub_off); pool_free(c, p->d_tmp); pool_free(c, p->d_P); pool_free(c, p->d_runs);
-    pool_free(c, p->d_rowcnt); pool_free(c, p->d_cptr);
+    pool_free(c, p->d_rowcnt); pool_free(c, p->d_cptr); pool_free(c, p->d_lists);
     delete p;
 }
 extern "C" int64_t smm_plan_nnz(const smm_plan *p) { return p ? p->nnz : -1; }
@@ -680,13 +693,25 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "symbolic phase: %s", hipGetErrorString(e)); }
     }
     if (gbm) pool_free(c, gbm);
-    if (p->b_sorted && p->nnz > 0) {
+    if (p->nnz > 0) {
+        // bin the rows of C: few nonzeros -> LDS hash kernels, the rest -> dense LDS tiles
+        PCHK(pool_get(c, (size_t)3 * m, &p->d_lists));
+        int *d_counts = (int *)((char *)c->d_flags + 192);
+        hipError_t e = hipMemsetAsync(d_counts, 0, 3 * sizeof(int), c->stream);
+        LAUNCH(c, "smm_bin_rows", smm_bin_rows, std::min<int64_t>((m + 255) / 256, 4096), 256, 0, (int)m, c->hash_small,
+               c->hash_medium, (const int *)p->d_rowcnt, p->d_lists, d_counts);
+        if (e == hipSuccess) e = hipMemcpyAsync(p->n_bin, d_counts, 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "row binning: %s", hipGetErrorString(e)); }
+    }
+    if (p->b_sorted && p->n_bin[2] > 0) {
         PCHK(ensure_seg(c, b, p->g));
         PCHK(ensure_loc(c, b, p->g));
         PCHK(pool_get(c, (size_t)a->nnz * (p->g.nct + 1), &p->d_runs));
-        const int rgrid = (int)std::min<int64_t>((m + 3) / 4, 65536);
-        LAUNCH(c, "smm_runs", smm_runs, rgrid, 256, 0, (int)m, p->g.nct, p->g.wc, a->ptr, p->d_ub_off, p->d_rowcnt,
-               p->d_P, p->d_tmp, p->d_runs);
+        const int nd = p->n_bin[2];
+        const int rgrid = (int)std::min<int64_t>((nd + 3) / 4, 65536);
+        LAUNCH(c, "smm_runs", smm_runs, rgrid, 256, 0, nd, p->g.nct, p->g.wc, (const int *)(p->d_lists + 2 * m), a->ptr,
+               p->d_ub_off, p->d_rowcnt, p->d_P, p->d_tmp, p->d_runs);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "smm_runs: %s", hipGetErrorString(e)); }
     }
@@ -707,30 +732,65 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
     if (p->nnz == 0) return SMM_OK;
     if (!d_c_indices || !d_c_data) return fail(SMM_ERR_INVALID, "output arrays are NULL but nnz > 0");
     const bool sym = p->flags & SMM_SYMMETRIC;
+    const bool exact = (p->flags & SMM_EXACT) != 0;
+    // rows with few nonzeros: LDS hash kernels (whole rows of B; B need not be sorted)
+    if (p->n_bin[0] > 0 || p->n_bin[1] > 0) {
+        HashArgs H{};
+        H.row_offset = p->row_offset;
+        H.a_ptr = p->a->ptr; H.a_idx = p->a->idx; H.a_val = p->a->val;
+        H.b_ptr = p->b->ptr; H.b_idx = p->b->idx; H.b_val = p->b->val;
+        H.c_ptr = p->d_cptr; H.c_idx = d_c_indices; H.c_val = d_c_data;
+        H.ub_off = p->d_ub_off; H.tmp_idx = p->d_tmp;
+        H.dummy_idx = (const int *)((const char *)c->d_flags + 64);
+        H.dummy_val = (const double *)((const char *)c->d_flags + 128);
+        if (p->n_bin[0] > 0) {      // one wave per row, four rows per workgroup (always reference order)
+            H.nrows = p->n_bin[0]; H.rowlist = p->d_lists;
+            const int grid = (int)std::min<int64_t>((H.nrows + 3) / 4, (int64_t)c->n_cu * 32);
+            if (sym) LAUNCH(c, "smm_numeric_hash", (smm_numeric_hash<true, 512, 1, 4>), grid, 256, 0, H);
+            else     LAUNCH(c, "smm_numeric_hash", (smm_numeric_hash<false, 512, 1, 4>), grid, 256, 0, H);
+        }
+        if (p->n_bin[1] > 0) {      // one workgroup per row; SMM_EXACT: a single wave keeps the order
+            H.nrows = p->n_bin[1]; H.rowlist = p->d_lists + m;
+            const int grid = (int)std::min<int64_t>(H.nrows, (int64_t)c->n_cu * 16);
+            if (exact) {
+                if (sym) LAUNCH(c, "smm_numeric_hash", (smm_numeric_hash<true, 4096, 1, 1>), grid, 64, 0, H);
+                else     LAUNCH(c, "smm_numeric_hash", (smm_numeric_hash<false, 4096, 1, 1>), grid, 64, 0, H);
+            } else {
+                if (sym) LAUNCH(c, "smm_numeric_hash", (smm_numeric_hash<true, 4096, 4, 1>), grid, 256, 0, H);
+                else     LAUNCH(c, "smm_numeric_hash", (smm_numeric_hash<false, 4096, 4, 1>), grid, 256, 0, H);
+            }
+        }
+        LAUNCH_CHECK();
+    }
+    if (p->n_bin[2] == 0) return SMM_OK;
+    const int nd = p->n_bin[2];
+    const int *dense_rows = p->d_lists + 2 * m;
     if (p->b_sorted) {
         NumericArgs A{};
-        A.m = (int)m; A.ncols = (int)p->ncols; A.nct = p->g.nct; A.wc = p->g.wc; A.wf = p->g.wf; A.n_ft = p->g.n_ft;
+        A.m = nd; A.ncols = (int)p->ncols; A.nct = p->g.nct; A.wc = p->g.wc; A.wf = p->g.wf; A.n_ft = p->g.n_ft;
         A.row_offset = p->row_offset;
+        A.rowlist = dense_rows;
         A.a_ptr = p->a->ptr; A.a_idx = p->a->idx; A.a_val = p->a->val;
         A.b_idx = p->b->idx; A.b_val = p->b->val; A.seg = p->b->seg; A.b_loc = p->b->loc;
         A.c_ptr = p->d_cptr; A.c_idx = d_c_indices; A.c_val = d_c_data;
         A.ub_off = p->d_ub_off; A.tmp_idx = p->d_tmp; A.runs = p->d_runs;
-        CHK(launch_numeric<OUT_SPARSE>(c, A, sym, p->g.nw, (p->flags & SMM_EXACT) != 0));
+        CHK(launch_numeric<OUT_SPARSE>(c, A, sym, p->g.nw, exact));
     } else {
-        const int cgrid = (int)std::min<int64_t>(m, 65536);
-        LAUNCH(c, "smm_copy_lists", smm_copy_lists, cgrid, 256, 0, (int)m, p->d_ub_off, p->d_cptr, p->d_tmp, d_c_indices);
+        const int cgrid = (int)std::min<int64_t>(nd, 65536);
+        LAUNCH(c, "smm_copy_lists", smm_copy_lists, cgrid, 256, 0, nd, dense_rows, p->d_ub_off, p->d_cptr, p->d_tmp,
+               d_c_indices);
         LAUNCH_CHECK();
-        const int grid = (int)std::min<int64_t>((m + 3) / 4, (int64_t)c->n_cu * 2);
+        const int grid = (int)std::min<int64_t>((nd + 3) / 4, (int64_t)c->n_cu * 2);
         int *slot = nullptr;
         CHK(pool_get(c, (size_t)grid * 4 * (size_t)p->ncols, &slot));
         if (sym)
-            LAUNCH(c, "smm_numeric_general", smm_numeric_general<true>, grid, 256, 0, (int)m, (int)p->ncols,
-                   p->row_offset, p->a->ptr, p->a->idx, p->a->val, p->b->ptr, p->b->idx, p->b->val, p->d_cptr,
-                   d_c_indices, d_c_data, slot);
+            LAUNCH(c, "smm_numeric_general", smm_numeric_general<true>, grid, 256, 0, nd, (int)p->ncols,
+                   p->row_offset, dense_rows, p->a->ptr, p->a->idx, p->a->val, p->b->ptr, p->b->idx, p->b->val, p->d_cptr,
+                   (const int *)d_c_indices, d_c_data, slot);
         else
-            LAUNCH(c, "smm_numeric_general", smm_numeric_general<false>, grid, 256, 0, (int)m, (int)p->ncols,
-                   p->row_offset, p->a->ptr, p->a->idx, p->a->val, p->b->ptr, p->b->idx, p->b->val, p->d_cptr,
-                   d_c_indices, d_c_data, slot);
+            LAUNCH(c, "smm_numeric_general", smm_numeric_general<false>, grid, 256, 0, nd, (int)p->ncols,
+                   p->row_offset, dense_rows, p->a->ptr, p->a->idx, p->a->val, p->b->ptr, p->b->idx, p->b->val, p->d_cptr,
+                   (const int *)d_c_indices, d_c_data, slot);
         LAUNCH_CHECK();
         HIPCHK(hipStreamSynchronize(c->stream));
         pool_free(c, slot);

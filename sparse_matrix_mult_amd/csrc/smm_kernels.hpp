@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, i
 // Sub-run table.  Step e of a row appended the columns list[P[e] .. P[e+1]) in ascending
 // order (B's rows are sorted), so the part that falls into coarse tile t is the contiguous
 // slot range [runs[e][t], runs[e][t+1]).  One lane per A entry, nct-1 lower_bounds each.
-__global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc,
+__global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc, const int *__restrict__ rowlist,
                                                 const int *__restrict__ a_ptr,
                                                 const int64_t *__restrict__ ub_off,
                                                 const int *__restrict__ rowcnt,
@@ -339,7 +339,8 @@ __global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc,
 {
     const int lane = lane_id();
     const int wpb = blockDim.x / WAVE;
-    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < m; row += gridDim.x * wpb) {
+    for (int ri = blockIdx.x * wpb + (threadIdx.x >> 6); ri < m; ri += gridDim.x * wpb) {
+        const int row = rowlist ? rowlist[ri] : ri;
         const int a0 = a_ptr[row], a1 = a_ptr[row + 1];
         const int *__restrict__ list = tmp_idx + ub_off[row];
         const unsigned total = (unsigned)rowcnt[row];
@@ -404,6 +405,7 @@ struct NumericArgs {
     const int64_t *c_ptr; int *c_idx; double *c_val;
     const int64_t *ub_off; const int *tmp_idx;   // ordered column lists of smm_symbolic
     const unsigned *runs;           // [nnzA][nct+1] sub-run table (smm_runs)
+    const int *rowlist;             // rows handled by this launch (NULL = all m rows)
     unsigned long long *stamps;     // diagnostic builds (-DSMM_STAMPS) only: 4 phase totals
     // dense output
     double *c_dense; int64_t ldc;
@@ -632,7 +634,8 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
 #define SMM_LAP(var)
 #endif
     const int tc = blockIdx.x / A.m;            // tile-major: concurrent units share B's slab
-    const int row = blockIdx.x - tc * A.m;
+    const int ridx = blockIdx.x - tc * A.m;
+    const int row = A.rowlist ? A.rowlist[ridx] : ridx;
     const int a0 = A.a_ptr[row], a1 = A.a_ptr[row + 1];
     const int64_t gi = row + A.row_offset;
     const int lo_c = tc * A.wc;
@@ -713,14 +716,166 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
 }
 
 // ---------------------------------------------------------------------------------------
+// Row binning after the symbolic phase: rows of C with few nonzeros go to the hash kernels
+// below, the rest to the dense-tile kernel above.  lists[b] receives the rows of bin b (order
+// irrelevant), counts[b] their number.  bin 0: 1..small_max, bin 1: ..med_max, bin 2: larger.
+__global__ __launch_bounds__(256) void smm_bin_rows(int m, int small_max, int med_max,
+                                                    const int *__restrict__ rowcnt,
+                                                    int *__restrict__ lists, int *__restrict__ counts)
+{
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < m; row += gridDim.x * blockDim.x) {
+        const int n = rowcnt[row];
+        if (n <= 0) continue;
+        const int b = n <= small_max ? 0 : (n <= med_max ? 1 : 2);
+        lists[(size_t)b * m + atomicAdd(&counts[b], 1)] = row;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Numeric phase for rows with few nonzeros: an LDS hash table column -> slot, where slot is the
+// column's position in the row's first-touch list (smm_symbolic), and one f64 accumulator per
+// slot.  The dense tile above costs O(columns of B) per row whatever the row holds; this costs
+// O(products + nonzeros), and its output is in the reference's order by construction
+// (values[slot]), fully coalesced.  It walks whole rows of B, so B need not be sorted.
+//   team = NW waves per row (TPB teams per workgroup); HSIZE >= 2 x nonzeros of the row.
+//   NW == 1: one wave adds the row's products in the reference's order -> bit-exact values
+//   (used for SMM_EXACT and for the small bin); NW > 1: the waves split A's entries (atomics).
+struct HashArgs {
+    int nrows;                      // rows in rowlist
+    int64_t row_offset;
+    const int *rowlist;
+    const int *a_ptr, *a_idx; const double *a_val;
+    const int *b_ptr, *b_idx; const double *b_val;
+    const int64_t *c_ptr; int *c_idx; double *c_val;
+    const int64_t *ub_off; const int *tmp_idx;
+    const int *dummy_idx; const double *dummy_val;
+};
+
+constexpr int HASH_UNROLL = 8;
+
+template <bool SYM, int HSIZE, int NW, int TPB>
+__global__ __launch_bounds__(NW * TPB * 64) void smm_numeric_hash(const HashArgs A)
+{
+    constexpr int HBITS = __builtin_ctz(HSIZE);
+    constexpr int NVAL = HSIZE / 2;
+    __shared__ int keys_s[TPB][HSIZE];
+    __shared__ unsigned short slots_s[TPB][HSIZE];
+    __shared__ double vals_s[TPB][NVAL];
+    const int lane = lane_id();
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int team = wid / NW, wave = wid % NW;
+    const int tlane = wave * WAVE + lane;              // lane index inside the team
+    constexpr int TN = NW * WAVE;
+    int *__restrict__ keys = keys_s[team];
+    unsigned short *__restrict__ slots = slots_s[team];
+    double *__restrict__ vals = vals_s[team];
+    auto team_sync = [&]() { if (NW * TPB > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
+    auto hash = [&](int c) { return (int)(((unsigned)c * 0x9E3779B1u) >> (32 - HBITS)); };
+
+    for (int ri = blockIdx.x * TPB + team; ri - team < A.nrows; ri += gridDim.x * TPB) {
+        // (every team of a workgroup runs the same number of iterations: the barriers are workgroup-wide)
+        const bool have = ri < A.nrows;
+        const int row = have ? A.rowlist[ri] : 0;
+        const int64_t rs = have ? A.c_ptr[row] : 0;
+        const int cnt = have ? (int)(A.c_ptr[row + 1] - rs) : 0;
+        const int *__restrict__ list = A.tmp_idx + (have ? A.ub_off[row] : 0);
+        // 1. empty table, accumulators at -0.0 (additive identity: reproduces `values[i] = p`)
+        for (int h = tlane; h < HSIZE; h += TN) keys[h] = -1;
+        for (int s = tlane; s < cnt; s += TN) vals[s] = -0.0;
+        team_sync();
+        // 2. insert the row's columns: slot = position in the first-touch list
+        for (int s = tlane; s < cnt; s += TN) {
+            const int c = list[s];
+            int h = hash(c);
+            while (atomicCAS(&keys[h], -1, c) != -1) h = (h + 1) & (HSIZE - 1);
+            slots[h] = (unsigned short)s;
+        }
+        team_sync();
+        // 3. products: wave w of the team takes A's entries w, w+NW, ... (whole rows of B)
+        if (have && cnt > 0) {
+            const int a0 = A.a_ptr[row], a1 = A.a_ptr[row + 1];
+            int thresh = 0;
+            if (SYM) { const int64_t gi = row + A.row_offset; thresh = gi > 0x7fffffff ? 0x7fffffff : (int)gi; }
+            auto load_a = [&](int jb, int &r, double &av) {
+                int e = jb + lane;
+                e = e < a1 ? e : a1 - 1;
+                r = A.a_idx[e];
+                av = A.a_val[e];
+            };
+            int r_c, r_n;
+            double a_c, a_n;
+            load_a(a0, r_c, a_c);
+            load_a(a0 + WAVE, r_n, a_n);
+            int bs = A.b_ptr[r_c], be = A.b_ptr[r_c + 1];
+            for (int jb = a0; jb < a1; jb += WAVE) {
+                const int rem = a1 - jb;
+                const int nb = rem < WAVE ? rem : WAVE;
+                const int bs_n = A.b_ptr[r_n], be_n = A.b_ptr[r_n + 1];
+                int r_nn;
+                double a_nn;
+                load_a(jb + 2 * WAVE, r_nn, a_nn);
+                int j = wave - NW, kb = 0, en = 0;
+                double aj = 0.0;
+                auto advance = [&]() {                                  // next own entry with a non-empty row of B
+                    do {
+                        j += NW;
+                        if (j >= nb) break;
+                        kb = rl(bs, j);
+                        en = rl(be, j);
+                        aj = rl(a_c, j);
+                    } while (kb >= en);
+                };
+                advance();
+                while (j < nb) {
+                    int c[HASH_UNROLL];
+                    double v[HASH_UNROLL], a[HASH_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < HASH_UNROLL; ++u) {             // all loads first
+                        const bool live = j < nb;
+                        const int k = kb + lane;
+                        const bool ok = live && k < en;
+                        const int *ip = ok ? A.b_idx + k : A.dummy_idx;
+                        const double *vp = ok ? A.b_val + k : A.dummy_val;
+                        c[u] = *ip;
+                        v[u] = *vp;
+                        a[u] = aj;
+                        kb += WAVE;
+                        if (live && kb >= en) advance();
+                    }
+#pragma unroll
+                    for (int u = 0; u < HASH_UNROLL; ++u) {
+                        if (c[u] >= thresh) {                           // also drops the dummy -1
+                            int h = hash(c[u]);
+                            while (keys[h] != c[u]) h = (h + 1) & (HSIZE - 1);
+                            lds_add(&vals[slots[h]], a[u] * v[u]);
+                        }
+                    }
+                }
+                bs = bs_n; be = be_n; a_c = a_n;
+                r_n = r_nn; a_n = a_nn;
+            }
+        }
+        team_sync();
+        // 4. the row, in first-touch order
+        for (int s = tlane; s < cnt; s += TN) {
+            A.c_idx[rs + s] = list[s];
+            A.c_val[rs + s] = vals[s];
+        }
+        team_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Copy the ordered lists from their capacity-strided slots to the CSR index array (only the
 // general path below needs it; smm_numeric emits indices itself).
-__global__ __launch_bounds__(256) void smm_copy_lists(int m, const int64_t *__restrict__ ub_off,
+__global__ __launch_bounds__(256) void smm_copy_lists(int m, const int *__restrict__ rowlist,
+                                                      const int64_t *__restrict__ ub_off,
                                                       const int64_t *__restrict__ c_ptr,
                                                       const int *__restrict__ tmp_idx,
                                                       int *__restrict__ c_idx)
 {
-    for (int row = blockIdx.x; row < m; row += gridDim.x) {
+    for (int ri = blockIdx.x; ri < m; ri += gridDim.x) {
+        const int row = rowlist ? rowlist[ri] : ri;
         const int64_t src = ub_off[row], dst = c_ptr[row];
         const int n = (int)(c_ptr[row + 1] - dst);
         for (int s = threadIdx.x; s < n; s += blockDim.x) c_idx[dst + s] = tmp_idx[src + s];
@@ -734,6 +889,7 @@ __global__ __launch_bounds__(256) void smm_copy_lists(int m, const int64_t *__re
 // agree to rounding (atomics), indices are untouched.  Correctness path, not a fast path.
 template <bool SYM>
 __global__ __launch_bounds__(256) void smm_numeric_general(int m, int ncols, int64_t row_offset,
+                                                           const int *__restrict__ rowlist,
                                                            const int *__restrict__ a_ptr,
                                                            const int *__restrict__ a_idx,
                                                            const double *__restrict__ a_val,
@@ -748,7 +904,8 @@ __global__ __launch_bounds__(256) void smm_numeric_general(int m, int ncols, int
     const int lane = lane_id();
     const int wpb = blockDim.x / WAVE;
     int *map = slotmap + ((size_t)blockIdx.x * wpb + (threadIdx.x >> 6)) * (size_t)ncols;
-    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < m; row += gridDim.x * wpb) {
+    for (int ri = blockIdx.x * wpb + (threadIdx.x >> 6); ri < m; ri += gridDim.x * wpb) {
+        const int row = rowlist ? rowlist[ri] : ri;
         const int64_t rs = c_ptr[row];
         const int n = (int)(c_ptr[row + 1] - rs);
         const int64_t gi = row + row_offset;

@@ -56,6 +56,11 @@ class Context:
         """Geometry of the default shared-tile walk (waves 4/8/16)."""
         check(self.lib, self.lib.smm_ctx_tune_shared(self.handle, int(lds_cols), int(waves)))
 
+    def tune_hash(self, small_max=256, medium_max=2048):
+        """Rows of C with at most small_max / medium_max nonzeros use the LDS-hash kernels
+        (0, 0 = dense LDS tiles for every row)."""
+        check(self.lib, self.lib.smm_ctx_tune_hash(self.handle, int(small_max), int(medium_max)))
+
     def timing(self, enable=True):
         check(self.lib, self.lib.smm_ctx_timing(self.handle, 1 if enable else 0))
 

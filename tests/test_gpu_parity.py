@@ -14,6 +14,17 @@ from helpers import arrays, assert_csr_equal, rand_csr, rel_err, shuffle_rows, s
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=["hash+tiles", "tiles-only", "small-hash"], autouse=True)
+def numeric_paths(request, ctx):
+    """Every case runs with the default dispatch (rows with few nonzeros -> LDS hash kernels, the
+    rest -> dense LDS tiles), with the hash kernels off, and with only the one-wave hash kernel
+    on and a low threshold (mixes all three kernels inside one product)."""
+    cfg = {"hash+tiles": (256, 2048), "tiles-only": (0, 0), "small-hash": (24, 150)}[request.param]
+    ctx.tune_hash(*cfg)
+    yield
+    ctx.tune_hash(256, 2048)
+
 RTOL = 1e-10   # north star: "float64 values within 1e-10 relative"
 
 CASES = [
