@@ -57,13 +57,12 @@ struct smm_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool timing = false;
-    int lds_cols = 20000;    // SMM_EXACT walk: accumulator columns per workgroup (x8 B of LDS) ...
-    int waves = 8;           // ... and waves per workgroup (each owns lds_cols/waves columns)
+    int lds_cols = 17000;    // SMM_EXACT walk: accumulator columns per workgroup (x8 B of LDS; 1.25 KB of
+    int waves = 16;          // scratch per wave sit behind them) and waves per workgroup (each owns 1/waves)
     int lds_cols_shared = 20000;   // default (shared-tile) walk: tile columns and waves per workgroup
     int waves_shared = 16;
     int hash_small = 256;    // rows of C with <= hash_small nonzeros: one wave per row, LDS hash (0 = off)
     int hash_medium = 2048;  // ... <= hash_medium: one workgroup per row, LDS hash; above: dense LDS tiles
-    int seg_target = 40;     // aimed-at entries of B per (row of B, fine tile) segment; <= 64 lanes
     int n_cu = 256;
     std::vector<PoolBlock> pool;          // free blocks
     std::map<void *, size_t> live;        // blocks handed out
@@ -248,7 +247,8 @@ extern "C" int smm_ctx_tune(smm_ctx *c, int lds_cols, int waves)
         c->lds_cols = lds_cols;
     }
     if (waves) {
-        if (waves != 1 && waves != 2 && waves != 4 && waves != 8) return fail(SMM_ERR_INVALID, "waves must be 1, 2, 4 or 8");
+        if (waves != 1 && waves != 2 && waves != 4 && waves != 8 && waves != 16)
+            return fail(SMM_ERR_INVALID, "waves must be 1, 2, 4, 8 or 16");
         c->waves = waves;
     }
     return SMM_OK;
@@ -403,21 +403,21 @@ static Geom make_geom(const smm_ctx *c, int64_t ncols, const smm_csr *b, bool ex
         g.n_ft = g.nct;
         return g;
     }
+    // exact walk: wave w of the workgroup owns fine tile w of the coarse tile; LDS also holds
+    // sizeof(ExactScratch) per wave behind the accumulators
     g.nw = c->waves;
     const int64_t cols = std::max<int64_t>(ncols, 1);
-    // fine-tile width: bounded by LDS, and by the width at which an average row of B leaves
-    // about seg_target entries per tile (one wave-load per segment, rarely more than 64)
-    int64_t wf_max = std::max<int64_t>(c->lds_cols / g.nw, 1);
-    if (b && b->rows > 0 && b->nnz > 0) {
-        const double avg_len = (double)b->nnz / (double)b->rows;
-        const int64_t cap = (int64_t)((double)c->seg_target * (double)cols / avg_len);
-        wf_max = std::min(wf_max, std::max<int64_t>(cap, 64));
-    }
-    const int64_t wc_max = wf_max * g.nw;
+    const int64_t lds_max = ((int64_t)160 * 1024 - (int64_t)g.nw * (int64_t)sizeof(ExactScratch)) / 8 - 2;
+    const int64_t wc_max = std::max<int64_t>(std::min<int64_t>(c->lds_cols, lds_max), g.nw);
     g.nct = (int)((cols + wc_max - 1) / wc_max);
     const int64_t per = (cols + g.nct - 1) / g.nct;
     g.wf = (int)((per + g.nw - 1) / g.nw);
     g.wc = g.wf * g.nw;
+    if (g.wc > wc_max) {                      // rounding up to a multiple of nw overshot the LDS budget
+        g.nct += 1;
+        g.wf = (int)(((cols + g.nct - 1) / g.nct + g.nw - 1) / g.nw);
+        g.wc = g.wf * g.nw;
+    }
     g.n_ft = g.nct * g.nw;
     return g;
 }
@@ -528,7 +528,8 @@ extern "C" int smm_row_products(smm_ctx *c, const smm_csr *a, const smm_csr *b, 
 template <int OUT, bool SYM, int NW, bool EXACT>
 static int launch_numeric_t(smm_ctx *c, NumericArgs &args)
 {
-    const size_t lds = (size_t)args.wc * sizeof(double);
+    // accumulator tile (+ the exact walk's per-wave scratch behind it)
+    const size_t lds = (size_t)((args.wc + 1) & ~1) * sizeof(double) + (EXACT ? (size_t)NW * sizeof(ExactScratch) : 0);
     auto kern = smm_numeric<OUT, SYM, NW, EXACT>;
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -566,6 +567,7 @@ static int launch_numeric(smm_ctx *c, NumericArgs &args, bool sym, int nw, bool 
     if (sym == S && nw == N && exact == X) return launch_numeric_t<OUT, S, N, X>(c, args);
     SMM_CASE(false, 1, true) SMM_CASE(true, 1, true) SMM_CASE(false, 2, true) SMM_CASE(true, 2, true)
     SMM_CASE(false, 4, true) SMM_CASE(true, 4, true) SMM_CASE(false, 8, true) SMM_CASE(true, 8, true)
+    SMM_CASE(false, 16, true) SMM_CASE(true, 16, true)
     SMM_CASE(false, 4, false) SMM_CASE(true, 4, false) SMM_CASE(false, 8, false) SMM_CASE(true, 8, false)
     SMM_CASE(false, 16, false) SMM_CASE(true, 16, false)
 #undef SMM_CASE

@@ -44,6 +44,15 @@ __device__ __forceinline__ int mbcnt(unsigned long long mask) {
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                           __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
+// Lanes of ONE wave that exchange data through LDS need no hardware barrier (the LDS executes a
+// wave's instructions in order), but the COMPILER must be told that other lanes may have
+// written: without a fence it optimises per thread (it once kept a lane's own `= 0` instead of
+// re-reading a word another lane had overwritten).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ void lds_add(double *p, double x) {
     // ds_add_f64 (no return): fire-and-forget, executed by the LDS in issue order
     (void)__hip_atomic_fetch_add(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -378,20 +387,13 @@ __global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc, const in
 //               staged the row in an L2-resident scratch row and gathered 8-byte elements from
 //               it spent half the kernel on those 2.5e9 L2 requests).
 // Two walks fill a tile:
-//   EXACT (SMM_EXACT): wave w owns fine tile w (columns [lo_c + w*wf, +wf)) and visits every A
-//     entry of the row in stored order, so every accumulator receives its products in exactly
-//     the reference's order (one wave's ds_add_f64 execute in issue order): sums are
-//     bit-identical to the CPU loop.  smm_accumulate.
+//   EXACT (SMM_EXACT): wave w owns fine tile w and adds the row's products in exactly the
+//     reference's order: sums are bit-identical to the CPU loop.  smm_accumulate.
 //   default: all waves share the tile and split the work by 64-entry chunks; sums agree to
-//     rounding.  smm_accumulate_shared (further down).
-//
-// The exact walk is a software pipeline (smm_accumulate): B's segments are 40-odd entries, far
-// too short to hide HBM/Infinity-Cache latency one at a time, and LDS capacity (20k f64
-// accumulators per CU) caps the CU at a handful of waves.  So each wave keeps PIPE = 32
-// segment loads (64 vector-memory ops, the vmcnt limit) in flight: step j adds the segment
-// loaded 32 steps ago and immediately re-issues its slot.  Every load in the loop is
-// unconditional (inactive lanes read a dummy word) so that the compiler's s_waitcnt
-// counts are exact -- a conditional load anywhere in the loop degrades them to vmcnt(0).
+//     rounding.  smm_accumulate_shared.
+// Every load in both walks is unconditional (idle lanes read a dummy word) so that the
+// compiler's s_waitcnt distances stay exact -- a predicated load inside the loop degrades
+// them to vmcnt(0).
 struct NumericArgs {
     int m, ncols, nct, wc, wf, n_ft;
     int64_t row_offset;
@@ -411,10 +413,30 @@ struct NumericArgs {
     double *c_dense; int64_t ldc;
 };
 
-constexpr int PIPE = 32;
+// Exact walk.  Wave w owns fine tile w of the coarse tile (columns [lo_c + w*wf, +wf)) and is the
+// only wave that ever adds into it, and it adds the row's products in exactly the reference's
+// order: A's entries in stored order, inside each the entries of B's row in stored order.  Two
+// hardware facts make that order cheap to keep:
+//   * the LDS executes one wave's ds_add_f64 instructions in issue order;
+//   * inside ONE ds_add_f64, lanes that hit the same address are applied in ascending lane order
+//     (not promised by the ISA; measured on gfx950 over 6.4e6 random accumulators with 0
+//     mismatches -- scripts/ubench/lds_order.hip -- and re-checked by every bit-exact test).
+// So the wave does not need one instruction per A entry: the fine-tile segments of 64 A entries
+// (about 10 entries of B each) are concatenated into one stream and consumed 64 lanes at a time,
+// lane order = stream order.  Which entry j a stream position belongs to is found without a
+// search: once per round of 8 chunks every entry drops its index at the stream position where
+// its segment starts (a 512-byte LDS scratch), a ballot marks those heads in each chunk, and
+// each lane takes the nearest head at or below it
+// (positions before the first head belong to the entry that straddles the chunk boundary,
+// counted with one more ballot).  Per-entry data (segment base, value of A) is then one LDS read.
+constexpr int EX_UNROLL = 8;
+struct ExactScratch {          // per wave, in LDS behind the accumulator tile
+    int4 tab[WAVE];            // .x = segment start - stream start (k = .x + position), .zw = bits of a
+    unsigned char head[WAVE * EX_UNROLL];   // one round of the stream: entry index + 1 where a segment starts
+};
 
 template <bool SYM>
-__device__ __forceinline__ void smm_accumulate(const NumericArgs &A, double *__restrict__ acc, const int lo_c,
+__device__ __forceinline__ void smm_accumulate(const NumericArgs &A, double *__restrict__ acc, ExactScratch *__restrict__ sc,
                                                const int thresh, const int a0, const int a1, const int ft)
 {
     const int lane = lane_id();
@@ -423,10 +445,8 @@ __device__ __forceinline__ void smm_accumulate(const NumericArgs &A, double *__r
     const short *__restrict__ bi = A.b_loc;
     const double *__restrict__ bv = A.b_val;
     const short *__restrict__ dummy_c = (const short *)A.dummy_idx;
-    int c[PIPE];
-    double v[PIPE];
+    const unsigned long long le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);   // lanes <= this one
 
-    // metadata of 64 A entries lives one-per-lane; all loads are clamped, never predicated
     auto load_a = [&](int jb, int &r, double &av) {
         int e = jb + lane;
         e = e < a1 ? e : a1 - 1;
@@ -438,90 +458,70 @@ __device__ __forceinline__ void smm_accumulate(const NumericArgs &A, double *__r
         s = sp[0];
         en = sp[1];
     };
-    auto issue = [&](int u, int s, int en) {          // s, en wave-uniform
-        const int k = s + lane;
-        const bool p = k < en;
-        const short *ip = p ? bi + k : dummy_c;
-        const double *vp = p ? bv + k : A.dummy_val;
-        c[u] = *ip;
-        v[u] = *vp;
-    };
-
-    auto long_tail = [&](double a, int s, int en) {   // rare: a segment longer than one wave
-        for (int base = s + WAVE; base < en; base += WAVE) {
-            const int k = base + lane;
-            if (k < en) {
-                const int c2 = bi[k];
-                if (c2 >= thresh) lds_add(&acc[c2], a * bv[k]);
-            }
-        }
-    };
 
     int r_c, r_n, s_c, e_c;
     double a_c, a_n;
     load_a(a0, r_c, a_c);
     load_a(a0 + WAVE, r_n, a_n);
     load_seg(r_c, s_c, e_c);
-    // keep these loads AHEAD of the 64 slot loads below: if the scheduler sinks them towards the
-    // loop, the loop header inherits a short vmcnt distance and drains the pipe every iteration
-    __builtin_amdgcn_sched_barrier(0);
-    {
-        const int nb0 = (a1 - a0) < WAVE ? (a1 - a0) : WAVE;
-#pragma unroll
-        for (int u = 0; u < PIPE; ++u) {
-            const bool ok = u < nb0;
-            const int s = rl(s_c, u), en = rl(e_c, u);
-            issue(u, ok ? s : 0, ok ? en : 0);
-        }
-    }
-    // Enter the loop with nothing pending (vmcnt(0); expcnt/lgkmcnt untouched).  The scheduler is
-    // free to reorder the prologue's loads, and whatever distance it leaves between a slot's load
-    // and the loop becomes the loop's own s_waitcnt -- executed every iteration, it would drain
-    // the pipe.  Draining once here costs nothing: step 0 needs the first slot anyway.
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __builtin_amdgcn_sched_barrier(0);
     for (int jb = a0; jb < a1; jb += WAVE) {
         const int rem = a1 - jb;
         const int nb = rem < WAVE ? rem : WAVE;
-        const int nbn = rem - WAVE < 0 ? 0 : (rem - WAVE < WAVE ? rem - WAVE : WAVE);
-        const unsigned long long longm = __ballot(e_c - s_c > WAVE);
         int s_n, e_n, r_nn;
         double a_nn;
         load_seg(r_n, s_n, e_n);                       // segments of the NEXT 64 entries
         load_a(jb + 2 * WAVE, r_nn, a_nn);             // A entries two batches ahead
-        // 64 steps, expanded by the preprocessor so that every slot / lane index is a literal
-        // (the slots must live in registers) and the only control flow is the exit.
-#define SMM_STEP(J)                                                                              \
-        {                                                                                        \
-            if ((J) >= nb) goto row_done;          /* wave-uniform; only in the LAST batch */    \
-            constexpr int u = (J) & (PIPE - 1);                                                  \
-            const double a = rl(a_c, (J));                                                       \
-            const int cc = c[u];                                                                 \
-            if (cc >= thresh) lds_add(&acc[cc], a * v[u]);                                       \
-            if ((longm >> (J)) & 1ull) long_tail(a, rl(s_c, (J)), rl(e_c, (J)));                 \
-            if ((J) < PIPE) {                      /* refill: entry J+32 of this batch ... */     \
-                const bool ok = (J) + PIPE < nb;                                                 \
-                const int s = rl(s_c, ((J) + PIPE) & 63), en = rl(e_c, ((J) + PIPE) & 63);       \
-                issue(u, ok ? s : 0, ok ? en : 0);                                               \
-            } else {                               /* ... or entry J-32 of the next batch */     \
-                const bool ok = (J) - PIPE < nbn;                                                \
-                const int s = rl(s_n, ((J) - PIPE) & 63), en = rl(e_n, ((J) - PIPE) & 63);       \
-                issue(u, ok ? s : 0, ok ? en : 0);                                               \
-            }                                                                                    \
+        // stream of this batch: entry j owns positions [first_j, first_j + len_j)
+        const int len = lane < nb ? e_c - s_c : 0;
+        int incl = len;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const int y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
         }
-#define SMM_STEP8(B) SMM_STEP(B) SMM_STEP(B + 1) SMM_STEP(B + 2) SMM_STEP(B + 3) \
-                     SMM_STEP(B + 4) SMM_STEP(B + 5) SMM_STEP(B + 6) SMM_STEP(B + 7)
-        SMM_STEP8(0) SMM_STEP8(8) SMM_STEP8(16) SMM_STEP8(24)
-        SMM_STEP8(32) SMM_STEP8(40) SMM_STEP8(48) SMM_STEP8(56)
-#undef SMM_STEP8
-#undef SMM_STEP
-        // (leaving through row_done instead of falling to the rotation keeps the back edge a
-        //  single straight-line path: its vmcnt distances are then exact, see header comment)
+        const int first = incl - len;
+        const int total = rl(incl, WAVE - 1);
+        sc->tab[lane] = make_int4(s_c - first, 0, __double2loint(a_c), __double2hiint(a_c));
+        wave_sync();
+        for (int g0 = 0; g0 < total; g0 += WAVE * EX_UNROLL) {
+            int c[EX_UNROLL];
+            double v[EX_UNROLL], a[EX_UNROLL];
+            // heads of this round (EX_UNROLL chunks): entries whose segment starts inside it
+            wave_sync();
+            ((unsigned long long *)sc->head)[lane] = 0ull;
+            wave_sync();
+            if (len > 0 && first >= g0 && first < g0 + WAVE * EX_UNROLL) sc->head[first - g0] = (unsigned char)(lane + 1);
+            wave_sync();
+#pragma unroll
+            for (int u = 0; u < EX_UNROLL; ++u) {       // map + load EX_UNROLL chunks ...
+                const int gbase = g0 + u * WAVE;        // wave-uniform
+                const int g = gbase + lane;
+                const int hd = sc->head[u * WAVE + lane];
+                const unsigned long long heads = __ballot(hd != 0);
+                // entry that owns the chunk's first position when no head precedes a lane
+                const int carry = (int)__popcll(__ballot(incl <= gbase));
+                const unsigned long long mine = heads & le_mask;
+                const int hl = 63 - __clzll((long long)(mine | 1ull));          // nearest head at or below
+                int j = __shfl(hd, hl) - 1;
+                if (mine == 0ull) j = carry;
+                j = j < WAVE ? j : WAVE - 1;
+                const int4 t = sc->tab[j];
+                const bool p = g < total;
+                const int k = t.x + g;
+                const short *ip = p ? bi + k : dummy_c;
+                const double *vp = p ? bv + k : A.dummy_val;
+                c[u] = *ip;
+                v[u] = *vp;
+                a[u] = __hiloint2double(t.w, t.z);
+            }
+#pragma unroll
+            for (int u = 0; u < EX_UNROLL; ++u)         // ... then add, lane order = stream order
+                if (c[u] >= thresh) lds_add(&acc[c[u]], a[u] * v[u]);
+        }
+        wave_sync();
         s_c = s_n; e_c = e_n; a_c = a_n;
         r_n = r_nn; a_n = a_nn;
     }
-row_done:
-    return;
 }
 
 // Shared-tile walk (default mode).  All NW waves of the workgroup add into the SAME coarse
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
     if (NW > 1) __syncthreads();
     SMM_LAP(t_init);
     if (!below && a1 > a0) {
-        if (EXACT) smm_accumulate<SYM>(A, acc, lo_c, thresh, a0, a1, tc * NW + wave);
+        if (EXACT) smm_accumulate<SYM>(A, acc, (ExactScratch *)(acc + ((A.wc + 1) & ~1)) + wave, thresh, a0, a1, tc * NW + wave);
         else       smm_accumulate_shared<SYM, NW>(A, acc, lo_c, thresh, a0, a1, tc, wave);
     }
     if (NW > 1) __syncthreads();
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(NW * TPB * 64) void smm_numeric_hash(const HashArgs
     int *__restrict__ keys = keys_s[team];
     unsigned short *__restrict__ slots = slots_s[team];
     double *__restrict__ vals = vals_s[team];
-    auto team_sync = [&]() { if (NW * TPB > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
+    auto team_sync = [&]() { if (NW * TPB > 1) __syncthreads(); else wave_sync(); };
     auto hash = [&](int c) { return (int)(((unsigned)c * 0x9E3779B1u) >> (32 - HBITS)); };
 
     for (int ri = blockIdx.x * TPB + team; ri - team < A.nrows; ri += gridDim.x * TPB) {

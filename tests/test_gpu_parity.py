@@ -69,7 +69,7 @@ def test_sparse_matches_oracle(ctx, oracle, m, k, n, da, db, symmetric, exact):
     assert_csr_equal(got, want, values=_check_values(exact), rtol=RTOL)
 
 
-@pytest.mark.parametrize("lds_cols,waves", [(64, 1), (256, 4), (512, 8), (1000, 2), (5000, 1), (16384, 4), (20000, 8)])
+@pytest.mark.parametrize("lds_cols,waves", [(64, 1), (256, 4), (512, 8), (1000, 2), (5000, 1), (16384, 4), (20000, 8), (17000, 16), (300, 16)])
 def test_sparse_tile_geometries(ctx, oracle, lds_cols, waves):
     """Every tile geometry must give the same bits (tiles only change who adds, not the order)."""
     A, B = signed(rand_csr(300, 400, 0.05, 3), 30), signed(rand_csr(400, 3000, 0.03, 4), 40)
@@ -78,7 +78,7 @@ def test_sparse_tile_geometries(ctx, oracle, lds_cols, waves):
     try:
         assert_csr_equal(_gpu_sparse(ctx, A, B, exact=True), want, values="bits")
     finally:
-        ctx.tune(20000, 8)
+        ctx.tune(17000, 16)
 
 
 @pytest.mark.parametrize("lds_cols,waves", [(64, 4), (300, 8), (1000, 16), (16384, 16), (20000, 8)])
