@@ -723,11 +723,21 @@ __global__ __launch_bounds__(256) void smm_bin_rows(int m, int small_max, int me
                                                     const int *__restrict__ rowcnt,
                                                     int *__restrict__ lists, int *__restrict__ counts)
 {
-    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < m; row += gridDim.x * blockDim.x) {
-        const int n = rowcnt[row];
-        if (n <= 0) continue;
-        const int b = n <= small_max ? 0 : (n <= med_max ? 1 : 2);
-        lists[(size_t)b * m + atomicAdd(&counts[b], 1)] = row;
+    const int lane = lane_id();
+    const int stride = gridDim.x * blockDim.x;
+    for (int base = blockIdx.x * blockDim.x + threadIdx.x - lane; base < m; base += stride) {   // wave-uniform trip count
+        const int row = base + lane;
+        const int n = row < m ? rowcnt[row] : 0;
+        const int b = n <= 0 ? -1 : (n <= small_max ? 0 : (n <= med_max ? 1 : 2));
+#pragma unroll
+        for (int bin = 0; bin < 3; ++bin) {                 // one atomic per wave and bin, not per row
+            const unsigned long long mask = __ballot(b == bin);
+            if (mask == 0ull) continue;
+            int at = 0;
+            if (lane == 0) at = atomicAdd(&counts[bin], (int)__popcll(mask));
+            at = rl(at, 0);
+            if (b == bin) lists[(size_t)bin * m + at + mbcnt(mask)] = row;
+        }
     }
 }
 
