@@ -611,7 +611,7 @@ __device__ __forceinline__ void smm_accumulate_shared(const NumericArgs &A, doub
 }
 
 #ifndef SMM_EPI_UNROLL
-#define SMM_EPI_UNROLL 4
+#define SMM_EPI_UNROLL 16
 #endif
 constexpr int EPI_UNROLL = SMM_EPI_UNROLL;
 
@@ -668,40 +668,49 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
         double *__restrict__ dst = A.c_dense + (int64_t)row * A.ldc + lo_c;
         for (int x = threadIdx.x; x < w; x += NT) dst[x] = acc[x];
     } else {
+        // Epilogue.  Step e of the row put its new columns of this tile into the contiguous slots
+        // [runs[e][tc], runs[e][tc+1]).  The sub-runs are cut into 64-lane chunks; wave w takes the
+        // entries w, w+NW, ... of a round of 32*NW entries (long sub-runs belong to the first steps,
+        // so interleaving balances them), and for its <= 32 entries it finds the chunk list with one
+        // scan, issues EPI_UNROLL chunk loads at a time and then stores.  The whole epilogue of a
+        // unit costs a handful of memory round trips (an earlier version walked the entries 64 at a
+        // time, one dependent round trip per batch and per long sub-run, and took 37 % of the kernel).
         const int *__restrict__ list = A.tmp_idx + A.ub_off[row];
         int *__restrict__ oi = A.c_idx + rs;
         double *__restrict__ ov = A.c_val + rs;
         const size_t per = (size_t)A.nct + 1;
-        for (int jb = a0; jb < a1; jb += WAVE) {
-            int e = jb + lane;
-            e = e < a1 ? e : a1 - 1;
-            const unsigned *rp = A.runs + (size_t)e * per + tc;
-            const unsigned r0 = rp[0], r1 = rp[1];
-            const int nb = (a1 - jb) < WAVE ? (a1 - jb) : WAVE;
-            for (int jj = wave; jj < nb; jj += NW * EPI_UNROLL) {
-                int c[EPI_UNROLL];
-                unsigned sl[EPI_UNROLL], s1[EPI_UNROLL];
+        for (int rb = a0; rb < a1; rb += NW * 32) {
+            const int e = rb + wave + NW * lane;
+            const bool ev = lane < 32 && e < a1;
+            const unsigned *rp = A.runs + (size_t)(ev ? e : a1 - 1) * per + tc;
+            const unsigned r0 = rp[0];
+            const unsigned r1 = ev ? rp[1] : r0;
+            const int nch = (int)((r1 - r0 + WAVE - 1) >> 6);
+            int incl = nch;
 #pragma unroll
-                for (int u = 0; u < EPI_UNROLL; ++u) {          // first chunk of EPI_UNROLL sub-runs
-                    const int j = jj + u * NW;
-                    const int jc = j < WAVE ? j : WAVE - 1;
-                    const unsigned s0 = rl(r0, jc);
-                    s1[u] = j < nb ? rl(r1, jc) : s0;
-                    sl[u] = s0 + (unsigned)lane;
-                    const int *ip = sl[u] < s1[u] ? list + sl[u] : A.dummy_idx;
+            for (int o = 1; o < WAVE; o <<= 1) {
+                const int y = __shfl_up(incl, o);
+                if (lane >= o) incl += y;
+            }
+            const int total = rl(incl, WAVE - 1);
+            for (int t0 = 0; t0 < total; t0 += EPI_UNROLL) {
+                int c[EPI_UNROLL];
+                unsigned sl[EPI_UNROLL];
+#pragma unroll
+                for (int u = 0; u < EPI_UNROLL; ++u) {          // all chunk loads of the round first
+                    const int t = t0 + u;
+                    int i = (int)__popcll(__ballot(incl <= t));
+                    i = i < WAVE ? i : WAVE - 1;
+                    const int first = rl(incl, i) - rl(nch, i);
+                    const unsigned s0 = rl(r0, i), s1 = rl(r1, i);
+                    sl[u] = s0 + ((unsigned)(t - first) << 6) + (unsigned)lane;
+                    const bool p = t < total && sl[u] < s1;
+                    const int *ip = p ? list + sl[u] : A.dummy_idx;
                     c[u] = *ip;
                 }
 #pragma unroll
-                for (int u = 0; u < EPI_UNROLL; ++u) {
+                for (int u = 0; u < EPI_UNROLL; ++u)
                     if (c[u] >= 0) { oi[sl[u]] = c[u]; ov[sl[u]] = acc[c[u] - lo_c]; }
-                    for (unsigned base = sl[u] + WAVE; base - lane < s1[u]; base += WAVE) {   // long sub-runs
-                        if (base < s1[u]) {
-                            const int c2 = list[base];
-                            oi[base] = c2;
-                            ov[base] = acc[c2 - lo_c];
-                        }
-                    }
-                }
             }
         }
     }
