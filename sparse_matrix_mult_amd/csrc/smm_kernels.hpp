@@ -533,7 +533,7 @@ __device__ __forceinline__ void smm_accumulate(const NumericArgs &A, double *__r
 // the reference to rounding (a few ulp; tests hold them to the north star's 1e-10) instead
 // of bit for bit.  SMM_EXACT selects smm_accumulate above instead.
 #ifndef SMM_CH_UNROLL
-#define SMM_CH_UNROLL 8
+#define SMM_CH_UNROLL 16
 #endif
 constexpr int CH_UNROLL = SMM_CH_UNROLL;
 
@@ -549,32 +549,19 @@ __device__ __forceinline__ void smm_accumulate_shared(const NumericArgs &A, doub
     const double *__restrict__ bv = A.b_val;
     const short *__restrict__ dummy_c = (const short *)A.dummy_idx;
 
-    auto load_a = [&](int jb, int &r, double &av) {
-        int e = jb + lane;
-        e = e < a1 ? e : a1 - 1;
-        r = A.a_idx[e];
-        av = A.a_val[e];
-    };
-    auto load_seg = [&](int r, int &s, int &en) {
+    // Wave w takes the A entries w, w+NW, ... of a round of 32*NW entries (the whole row when it
+    // has <= 512 entries): it alone loads their metadata (no NW-fold redundancy), cuts their
+    // segments into 64-lane chunks with one scan, and then issues CH_UNROLL chunk loads at a time.
+    for (int rb = a0; rb < a1; rb += NW * 32) {
+        const int e = rb + wave + NW * lane;
+        const bool ev = lane < 32 && e < a1;
+        const int ec = ev ? e : a1 - 1;
+        const int r = A.a_idx[ec];
+        const double av = A.a_val[ec];
         const int *sp = segf + (size_t)r * per;
-        s = sp[0];
-        en = sp[1];
-    };
-
-    int r_c, r_n, s_c, e_c;
-    double a_c, a_n;
-    load_a(a0, r_c, a_c);
-    load_a(a0 + WAVE, r_n, a_n);
-    load_seg(r_c, s_c, e_c);
-    for (int jb = a0; jb < a1; jb += WAVE) {
-        const int rem = a1 - jb;
-        const int nb = rem < WAVE ? rem : WAVE;
-        int s_n, e_n, r_nn;
-        double a_nn;
-        load_seg(r_n, s_n, e_n);                       // segments of the NEXT 64 entries
-        load_a(jb + 2 * WAVE, r_nn, a_nn);             // A entries two batches ahead
-        // chunk list of this batch: entry j owns chunks [incl_j - nch_j, incl_j)
-        const int nch = lane < nb ? ((e_c - s_c + WAVE - 1) >> 6) : 0;
+        const int s_l = sp[0];
+        const int e_l = ev ? sp[1] : s_l;
+        const int nch = (e_l - s_l + WAVE - 1) >> 6;
         int incl = nch;
 #pragma unroll
         for (int o = 1; o < WAVE; o <<= 1) {
@@ -582,20 +569,19 @@ __device__ __forceinline__ void smm_accumulate_shared(const NumericArgs &A, doub
             if (lane >= o) incl += y;
         }
         const int total = rl(incl, WAVE - 1);
-        for (int t0 = wave; t0 < total; t0 += NW * CH_UNROLL) {
-            int c[CH_UNROLL];
-            double v[CH_UNROLL], a[CH_UNROLL];
+        for (int t0 = 0; t0 < total; t0 += CH_UNROLL) {
+            int c[CH_UNROLL], own[CH_UNROLL];
+            double v[CH_UNROLL];
 #pragma unroll
             for (int u = 0; u < CH_UNROLL; ++u) {       // every load first ...
-                const int t = t0 + u * NW;
-                const bool ok = t < total;
-                int j = (int)__popcll(__ballot(incl <= t));
-                j = j < WAVE ? j : WAVE - 1;
-                const int first = rl(incl, j) - rl(nch, j);
-                const int s = rl(s_c, j), en = rl(e_c, j);
-                a[u] = rl(a_c, j);
+                const int t = t0 + u;
+                int i = (int)__popcll(__ballot(incl <= t));
+                i = i < WAVE ? i : WAVE - 1;
+                own[u] = i;
+                const int first = rl(incl, i) - rl(nch, i);
+                const int s = rl(s_l, i), en = rl(e_l, i);
                 const int k = s + ((t - first) << 6) + lane;
-                const bool p = ok && k < en;
+                const bool p = t < total && k < en;
                 const short *ip = p ? bi + k : dummy_c;
                 const double *vp = p ? bv + k : A.dummy_val;
                 c[u] = *ip;
@@ -603,10 +589,8 @@ __device__ __forceinline__ void smm_accumulate_shared(const NumericArgs &A, doub
             }
 #pragma unroll
             for (int u = 0; u < CH_UNROLL; ++u)         // ... then the adds
-                if (c[u] >= thresh) lds_add(&acc[c[u]], a[u] * v[u]);
+                if (c[u] >= thresh) lds_add(&acc[c[u]], rl(av, own[u]) * v[u]);
         }
-        s_c = s_n; e_c = e_n; a_c = a_n;
-        r_n = r_nn; a_n = a_nn;
     }
 }
 
