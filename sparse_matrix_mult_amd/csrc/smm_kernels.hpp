@@ -204,7 +204,10 @@ __global__ __launch_bounds__(1024) void smm_scan(int n, const T *__restrict__ in
 // through the rows of 64 A entries; SYM_UNROLL chunk loads are issued together
 // (unconditional: idle lanes read a dummy -1) and then consumed strictly in order.  The B-row
 // pointers of the next 64 entries and the A indices of the 64 after those are prefetched.
-constexpr int SYM_UNROLL = 16;
+#ifndef SMM_SYM_UNROLL
+#define SMM_SYM_UNROLL 16
+#endif
+constexpr int SYM_UNROLL = SMM_SYM_UNROLL;
 template <bool SYM, bool SAFE, bool LDSBM>
 __global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, int bm_words,
                                                     const int *__restrict__ a_ptr,
