@@ -57,8 +57,8 @@ struct smm_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool timing = false;
-    int lds_cols = 17000;    // SMM_EXACT walk: accumulator columns per workgroup (x8 B of LDS; 1.25 KB of
-    int waves = 16;          // scratch per wave sit behind them) and waves per workgroup (each owns 1/waves)
+    int lds_cols = 18000;    // SMM_EXACT walk: accumulator columns per workgroup (x8 B of LDS; 1.5 KB of
+    int waves = 8;           // scratch per wave sit behind them) and waves per workgroup (each owns 1/waves)
     int lds_cols_shared = 20000;   // default (shared-tile) walk: tile columns and waves per workgroup
     int waves_shared = 16;
     int hash_small = 256;    // rows of C with <= hash_small nonzeros: one wave per row, LDS hash (0 = off)

@@ -78,7 +78,7 @@ def test_sparse_tile_geometries(ctx, oracle, lds_cols, waves):
     try:
         assert_csr_equal(_gpu_sparse(ctx, A, B, exact=True), want, values="bits")
     finally:
-        ctx.tune(17000, 16)
+        ctx.tune(18000, 8)
 
 
 @pytest.mark.parametrize("lds_cols,waves", [(64, 4), (300, 8), (1000, 16), (16384, 16), (20000, 8)])

@@ -94,7 +94,7 @@ def test_random_sweep_small_tiles(ctx, oracle, lds_cols, waves):
         assert_csr_equal(ctx.spgemm_host(a, b, exact=True), want, values="bits")
         assert_csr_equal(ctx.spgemm_host(a, b), want, values="tol", rtol=RTOL)
     finally:
-        ctx.tune_shared(20000, 16); ctx.tune(17000, 16)
+        ctx.tune_shared(20000, 16); ctx.tune(18000, 8)
         a.close(); b.close()
 
 
