@@ -111,3 +111,32 @@ def test_triple_skewed(ctx, oracle):
             assert rel_err(ctx.triple_host(h, q, full=bool(full)), want) <= RTOL
     finally:
         h.close(); q.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz(ctx, oracle, seed):
+    """Random shapes / densities / value signs, both modes, sparse + dense + (square) symmetric."""
+    r = np.random.default_rng(1000 + seed)
+    m, k, n = (int(x) for x in r.integers(1, 400, size=3))
+    if seed % 3 == 0:
+        n = m                                              # square: exercises the symmetric variants
+    if seed % 5 == 0:
+        n = int(r.integers(3000, 30000))                   # several coarse tiles
+    da, db = (float(x) for x in 10 ** r.uniform(-2.5, -0.3, size=2))
+    A = sp.random(m, k, density=da, format="csr", random_state=r)
+    B = sp.random(k, n, density=db, format="csr", random_state=r)
+    A.data = r.uniform(-1, 1, size=A.nnz); B.data = r.uniform(-1, 1, size=B.nnz)
+    a, b = ctx.csr_from_scipy(A), ctx.csr_from_scipy(B)
+    try:
+        for symmetric in ((False, True) if m == n else (False,)):
+            want = oracle.sparse(arrays(A), arrays(B), n, symmetric=symmetric)
+            got = ctx.spgemm_host(a, b, symmetric=symmetric, exact=True)
+            assert_csr_equal(got, want, values="bits")
+            got = ctx.spgemm_host(a, b, symmetric=symmetric)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+            assert np.allclose(got[2], want[2], rtol=1e-9, atol=1e-12)     # signed data: cancellation
+            if m * n <= 4_000_000:
+                wd = oracle.dense(arrays(A), arrays(B), n, symmetric=symmetric)
+                assert np.array_equal(ctx.dense_host(a, b, symmetric=symmetric, exact=True).view(np.int64), wd.view(np.int64))
+    finally:
+        a.close(); b.close()
