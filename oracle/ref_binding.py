@@ -89,3 +89,49 @@ def limits(rows, nprocs):
     out = np.ctypeslib.as_array(r.array, shape=(2 * p,)).copy()
     lib().destroy_iarray(ctypes.byref(r))
     return p, out
+
+
+# ---- HEAD's row kernel with its marker array initialised to -1 (oracle/marker_init.c) ------------
+PATH_M1 = os.path.join(_HERE, "_ref", "libsparsework_m1.so")
+_LIB_M1 = None
+
+
+def m1_available():
+    return os.path.exists(PATH_M1)
+
+
+def sparsework(a, b, m, k, n, row_begin, row_end, symmetric=False):
+    """Runs the reference's sparsework_nosym/_sym (src/sparsework.cpp:12-149 / :156-300, unedited,
+    marker initialised to -1) on rows [row_begin,row_end).  Returns (per-row counts, colInd, values)."""
+    global _LIB_M1
+    if _LIB_M1 is None:
+        _LIB_M1 = ctypes.CDLL(PATH_M1)
+        sp = ctypes.POINTER(SparseMatSz)
+        for f in (_LIB_M1.sparsework_nosym, _LIB_M1.sparsework_sym):
+            f.argtypes = [sp, sp, sp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+            f.restype = None
+    fn = _LIB_M1.sparsework_sym if symmetric else _LIB_M1.sparsework_nosym
+    libc = ctypes.CDLL(None)
+    libc.free.argtypes = [ctypes.c_void_p]
+    nr = row_end - row_begin
+
+    def run(mem_increase):
+        sa, sb, out = _wrap(a, m, k), _wrap(b, k, n), SparseMatSz()
+        fn(ctypes.byref(sa), ctypes.byref(sb), ctypes.byref(out), row_begin, row_end - 1, mem_increase)
+        nnz = int(out.nzmax)
+        cnt = np.ctypeslib.as_array(out.rowPtr, shape=(nr,)).copy().astype(np.int64)
+        idx = np.ctypeslib.as_array(out.colInd, shape=(max(nnz, 1),))[:nnz].copy()
+        val = np.ctypeslib.as_array(out.values, shape=(max(nnz, 1),))[:nnz].copy()
+        libc.free(ctypes.cast(out.rowPtr, ctypes.c_void_p))  # rowPtr/colInd/values share one malloc pool (:32-42)
+        return nnz, cnt, idx, val
+
+    # HEAD lays colInd and values out behind each other in one pool and does not move `values`
+    # when the pool grows or shrinks (:81-103, :135-148), so the values come back intact only when
+    # the initial capacity equals the final nnz: first call for nnz (counts and colInd are
+    # position-stable), second call with exactly that capacity.
+    nnz, cnt, idx, _ = run(max(n, 64))
+    if nnz == 0:
+        return cnt, idx, np.zeros(0)
+    nnz2, cnt2, idx2, val = run(nnz)
+    assert nnz2 == nnz and np.array_equal(idx, idx2) and np.array_equal(cnt, cnt2)
+    return cnt, idx, val

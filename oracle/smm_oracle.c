@@ -4,12 +4,14 @@
  * (setup.py:142, `g++ -O3 -fPIC -std=c++11`, x86-64 baseline) has no FMA, so every
  * product is rounded before it is added.
  *
- * Parity status: dense / dense-sym / triple / limits are pinned against oracle/_ref (the
- * reference's own sources compiled here).  The sparse->sparse VALUES and PATTERN are
- * pinned against the same _ref dense results and against the reference tests' matrices;
- * the first-touch ORDER of colInd follows src/sparsework.cpp:106-110 as written, but
- * HEAD's sparse driver does not run, so the order itself is pinned by the
- * source text only ("order parity unpinned by execution").
+ * Parity status: dense / dense-sym / triple / limits are pinned bit for bit against
+ * oracle/_ref/libsparse_ref.so (the reference's own sources compiled here, unmodified).  The
+ * sparse->sparse routine is pinned three ways: values and pattern against the same reference-built
+ * dense results and the reference tests' matrices; per-row counts, the first-touch ORDER of
+ * colInd and the values against oracle/_ref/libsparsework_m1.so -- the reference's own
+ * src/sparsework.cpp, unedited, executed with its marker array initialised to -1
+ * (oracle/marker_init.c explains why HEAD needs that one value to run at all; DESIGN.md section 2
+ * states the caveat).
  */
 #include "smm_oracle.h"
 #include <stdlib.h>

@@ -6,12 +6,15 @@
 What is recorded, per case: the inputs (CSR arrays, explicitly -- RNG streams are
 version-dependent) and the outputs of the REFERENCE'S OWN CODE built from source
 (oracle/_ref/libsparse_ref.so: dense_nosym, dense_sym, triple_product with
-compute_full_matrix 0 and 1, limits).  HEAD's sparse_nosym/sparse_sym do not run (SURVEY
-F2) and the prebuilt binaries shipped inside the reference are never loaded, so for the
-sparse->sparse routines the file records what the reference's own tests assert instead:
-numpy's product of the same inputs (tests/test_matrix_multiply.py:89-112 compare with
-np.matmul under np.allclose).  The sparse VALUES are additionally pinned bit-for-bit by the
-reference-built dense results (same products, same order: SURVEY F4).
+compute_full_matrix 0 and 1, limits).  HEAD's sparse_nosym/sparse_sym drivers do not run
+ and the prebuilt binaries shipped inside the reference are never loaded.  For the
+sparse->sparse routines the file records (1) what the reference's own tests assert: numpy's
+product of the same inputs (tests/test_matrix_multiply.py:89-112 compare with np.matmul under
+np.allclose); (2) the reference-built dense results, which pin the sparse VALUES bit for bit
+(same products, same order: SURVEY F4); (3) `refloop_*`: per-row counts, colInd (the
+first-touch ORDER) and values produced by the reference's own row kernel src/sparsework.cpp --
+unedited, but linked so that its marker array starts at -1 (oracle/marker_init.c: HEAD's
+zero-filled marker makes the loop treat every product as already present).
 
 The matrices are the ones the reference's tests hold as data:
   tests/test_matrix_multiply.py:9-78  (A/B 8x8, C 9x12, D 12x6, F 12x9)
@@ -112,6 +115,13 @@ def main():
         out[f"{name}/numpy_matmul"] = dense_np
         if m == n:
             out[f"{name}/ref_dense_sym"] = rb.dense(a[1:], b[1:], m, k, n, True)
+        # first-touch ORDER by execution: the reference's own src/sparsework.cpp loop, unedited, with
+        # its marker array initialised to -1 (oracle/marker_init.c)
+        cnt, idx, val = rb.sparsework(a[1:], b[1:], m, k, n, 0, m, False)
+        out[f"{name}/refloop_counts"], out[f"{name}/refloop_indices"], out[f"{name}/refloop_values"] = cnt, idx, val
+        if m == n:
+            cnt, idx, _ = rb.sparsework(a[1:], b[1:], m, k, n, 0, m, True)
+            out[f"{name}/refloop_sym_counts"], out[f"{name}/refloop_sym_indices"] = cnt, idx
         # consistency of the restatement, checked at generation time
         p, i, v = oracle.sparse(a[1:], b[1:], n)
         assert np.array_equal(sp.csr_matrix((v, i, p), shape=(m, n)).toarray(), out[f"{name}/ref_dense"]), name

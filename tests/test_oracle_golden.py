@@ -64,6 +64,23 @@ def test_sparse_values_and_pattern_match_reference_build(oracle, case):
         assert np.all(rows <= idx)                                         # upper triangle only
 
 
+@pytest.mark.parametrize("case", CASES)
+def test_first_touch_order_matches_the_reference_loop(oracle, case):
+    """`refloop_*` = output of the reference's own row kernel (src/sparsework.cpp, unedited, marker
+    array initialised to -1 -- oracle/marker_init.c): per-row counts, colInd in first-touch order,
+    values.  The oracle must reproduce all three bit for bit (sym: counts and order)."""
+    a, b = _operand(case, "a"), _operand(case, "b")
+    m, n = int(GOLD[f"{case}/a_shape"][0]), int(GOLD[f"{case}/b_shape"][1])
+    cnt, idx, val = oracle.sparse_rows(a, b, n, 0, m)
+    assert np.array_equal(cnt, GOLD[f"{case}/refloop_counts"])
+    assert np.array_equal(idx, GOLD[f"{case}/refloop_indices"])
+    assert np.array_equal(val.view(np.int64), GOLD[f"{case}/refloop_values"].view(np.int64))
+    if f"{case}/refloop_sym_indices" in GOLD.files:
+        cnt, idx, _ = oracle.sparse_rows(a, b, n, 0, m, symmetric=True)
+        assert np.array_equal(cnt, GOLD[f"{case}/refloop_sym_counts"])
+        assert np.array_equal(idx, GOLD[f"{case}/refloop_sym_indices"])
+
+
 def test_first_touch_order_known_answer(oracle):
     """src/sparsework.cpp:59-110 by hand: row 0 of A visits B rows 2 then 0; columns appear in
     the order they are first produced, not sorted."""
@@ -124,3 +141,10 @@ def test_reference_build_still_agrees_when_present(oracle):
     A, B = rand_csr(70, 50, 0.2, 5), rand_csr(50, 70, 0.2, 6)
     assert np.array_equal(oracle.dense(arrays(A), arrays(B), 70), rb.dense(arrays(A), arrays(B), 70, 50, 70))
     assert np.array_equal(oracle.dense(arrays(A), arrays(B), 70, True), rb.dense(arrays(A), arrays(B), 70, 50, 70, True))
+    if rb.m1_available():
+        for sym in (False, True):
+            cnt, idx, val = rb.sparsework(arrays(A), arrays(B), 70, 50, 70, 10, 61, sym)
+            c2, i2, v2 = oracle.sparse_rows(arrays(A), arrays(B), 70, 10, 61, sym)
+            assert np.array_equal(cnt, c2) and np.array_equal(idx, i2)
+            if not sym:
+                assert np.array_equal(val, v2)
