@@ -32,6 +32,14 @@ static smm_ctx *legacy_ctx()
     return g_ctx;
 }
 
+// SMM_EXACT=1 in the environment selects reference-order accumulation (bit-identical values) for
+// the legacy symbols too, as sparse_matrix_mult_amd.set_exact() does for the Python API.
+static int legacy_mode_flags()
+{
+    const char *e = getenv("SMM_EXACT");
+    return (e && *e && strcmp(e, "0") != 0) ? SMM_EXACT : 0;
+}
+
 extern "C" {
 
 struct sparsemat *create_sparsemat(int rows, int cols, int nzmax)
@@ -154,7 +162,7 @@ void sparse_impl(const struct sparsemat *a, const struct sparsemat *b, struct sp
     if (!upload(c, a, A, row0, row1) || !upload(c, b, B)) return;
     smm_plan *plan = nullptr;
     int64_t nnz = 0;
-    if (smm_spgemm_symbolic(c, A.h, B.h, flags, row0, &plan, &nnz) != SMM_OK) {
+    if (smm_spgemm_symbolic(c, A.h, B.h, flags | legacy_mode_flags(), row0, &plan, &nnz) != SMM_OK) {
         fprintf(stderr, "libsmm_hip: %s\n", smm_last_error());
         return;
     }
@@ -199,7 +207,7 @@ void dense_impl(const struct sparsemat *a, const struct sparsemat *b, struct dar
     std::lock_guard<std::mutex> call_lock(g_call_mu);
     Operand A, B;
     if (!upload(c, a, A) || !upload(c, b, B) ||
-        smm_spgemm_dense_host(c, A.h, B.h, flags, 0, out->array) != SMM_OK) {
+        smm_spgemm_dense_host(c, A.h, B.h, flags | legacy_mode_flags(), 0, out->array) != SMM_OK) {
         fprintf(stderr, "libsmm_hip: %s\n", smm_last_error());
         free(out->array); out->array = nullptr;
     }
@@ -257,7 +265,8 @@ void triple_product(struct sparsemat *h, struct sparsemat *q, struct darray *out
     std::lock_guard<std::mutex> call_lock(g_call_mu);
     Operand H, Q;
     if (!upload(c, h, H) || !upload(c, q, Q) ||
-        smm_triple_product_host(c, H.h, Q.h, compute_full_matrix ? SMM_FULL_MATRIX : 0, 0, n, out->array) != SMM_OK) {
+        smm_triple_product_host(c, H.h, Q.h, (compute_full_matrix ? SMM_FULL_MATRIX : 0) | legacy_mode_flags(), 0, n,
+                                out->array) != SMM_OK) {
         fprintf(stderr, "libsmm_hip: %s\n", smm_last_error());
         free(out->array); out->array = nullptr;
     }
