@@ -484,8 +484,9 @@ static int ensure_ell(smm_ctx *c, smm_csr *h, int nchunks, int chunk)
     HIPCHK(hipMemcpyAsync(&total, h->ell_off + items, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     pool_free(c, cnt);
-    if (hipMalloc((void **)&h->ell_col, std::max<int64_t>(total, 1) * sizeof(short)) != hipSuccess ||
-        hipMalloc((void **)&h->ell_val, std::max<int64_t>(total, 1) * sizeof(double)) != hipSuccess)
+    // + one wave of slack: stage 2 requests step 0 of a block before it knows the block is empty
+    if (hipMalloc((void **)&h->ell_col, (total + WAVE) * sizeof(short)) != hipSuccess ||
+        hipMalloc((void **)&h->ell_val, (total + WAVE) * sizeof(double)) != hipSuccess)
         return fail(SMM_ERR_ALLOC, "hipMalloc of the ELL payload (%lld entries) failed", (long long)total);
     E.col = h->ell_col; E.val = h->ell_val;
     LAUNCH(c, "smm_ell_fill", smm_ell_fill, grid, 256, 0, E);
@@ -927,24 +928,27 @@ extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags,
     int rc = dense_into(c, &hv, q, flags & SMM_EXACT, 0, T, K);
     if (rc != SMM_OK) { pool_free(c, T); return rc; }
     // stage 2
-    constexpr int R = 8, NW = 16;
-    const int chunk_cap = 16384 / R;       // 128 KB of LDS for R tile rows
+    constexpr int NW = 16;
+    constexpr int R = 16;
+    const int chunk_cap = 1024;            // [chunk][R+2] f64 = 144 KB of LDS
     const int nchunks = (int)((K + chunk_cap - 1) / chunk_cap);
     const int chunk = (int)((K + nchunks - 1) / nchunks);
     rc = ensure_ell(c, h, nchunks, chunk);
     if (rc != SMM_OK) { pool_free(c, T); return rc; }
     TripleArgs A{};
     A.n = (int)n; A.K = (int)K; A.nchunks = nchunks; A.chunk = chunk; A.nslices = (int)((n + WAVE - 1) / WAVE);
+    A.nib = (int)((nr + R - 1) / R);
     A.row_begin = row_begin; A.row_end = row_end; A.full = full ? 1 : 0;
     A.len = h->ell_len; A.off = h->ell_off; A.col = h->ell_col; A.val = h->ell_val;
     A.T = T; A.C = d_c; A.ldc = n;
-    const size_t lds = (size_t)R * chunk * sizeof(double);
-    auto kern = smm_triple_stage2<R, NW>;
+    const size_t lds = (size_t)(R + 2) * chunk * sizeof(double);
+    const int64_t nkg = (n + NW * WAVE - 1) / (NW * WAVE);
+    auto kern = smm_triple_stage2<R, NW, 1024>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { pool_free(c, T); return fail(SMM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e)); }
     }
-    LAUNCH(c, "smm_triple_stage2", kern, (nr + R - 1) / R, NW * 64, lds, A);
+    LAUNCH(c, "smm_triple_stage2", kern, nkg * A.nib, NW * 64, lds, A);
     if (full) LAUNCH(c, "smm_triple_mirror", smm_triple_mirror, (n * n + 255) / 256, 256, 0, (int)n, d_c, n);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // T returns to the pool below

@@ -965,15 +965,20 @@ __global__ __launch_bounds__(256) void smm_dense_general(int m, int ncols, int64
 // (smm_numeric<OUT_DENSE>) left in HBM.  The sum runs in H's stored order starting from 0.0,
 // exactly as the reference's scalar loop, so stage 2 is bit-exact given T.
 //
-// Layout.  K is cut into chunks of `chunk` columns; a workgroup holds R rows of T for one chunk
-// in LDS ([R][chunk] f64 = 128 KB) and every lane owns one k: it walks the part of H's row k
-// that falls into the chunk and feeds R running sums.  Between chunks the running sums of a
-// row live in C itself; chunks are visited in ascending column order = stored order of a
-// sorted H, so the order of additions is the reference's.
+// Layout.  A workgroup owns a block of R rows of T and a group of NW*64 rows k of H (one k per
+// lane, one 64-row slice per wave); its R running sums per lane stay in registers from the
+// first column of H to the last.  K is cut into chunks of <= 512 columns; the R x chunk piece
+// of T sits in LDS column-major with a 2-double pad ([chunk][R+2]: the R values of one column
+// are one contiguous run, read with ds_read_b128; the pad spreads a wave's random columns over
+// all banks -- 1.46x the gather rate of the row-major tile it replaced,
+// scripts/ubench/lds_gather.hip).  Chunks are visited in ascending column order = stored order
+// of a sorted H, so the order of additions is the reference's.
 // A lane walking its own CSR row would make every load 64 separate 12-byte requests, so H is
 // re-laid once (cached on the handle) as sliced ELL per chunk: for 64 consecutive rows k and
 // chunk q, step s of all 64 rows is stored contiguously -- int16 chunk-local column + f64
-// value -- padded to the longest of the 64 segments (rows of H are ~equal length: ~10-15 %).
+// value -- padded to the longest of the 64 segments.
+// Traffic: the ELL copy of H is streamed once per row block (n/R times; consecutive workgroups
+// share one k-group, so it is served by the Infinity Cache), T once per k-group.
 struct EllArgs {
     int n, nchunks, chunk, nslices;
     const int *h_ptr, *h_idx; const double *h_val;
@@ -1029,6 +1034,7 @@ __global__ __launch_bounds__(256) void smm_ell_fill(const EllArgs A)
 
 struct TripleArgs {
     int n, K, nchunks, chunk, nslices;
+    int nib;                          // row blocks; blockIdx.x = kgroup * nib + row block
     int64_t row_begin, row_end;
     int full;
     const int *len;                   // [nchunks][n]
@@ -1038,60 +1044,122 @@ struct TripleArgs {
     double *C; int64_t ldc;           // row row_begin at C
 };
 
-template <int R, int NW>
+template <int R, int NW, int CW>
 __global__ __launch_bounds__(NW * 64) void smm_triple_stage2(const TripleArgs A)
 {
-    extern __shared__ double tl[];                     // [R][chunk]
+    constexpr int RP = NW * 64 / CW;                   // tile rows filled per pass (chunk <= CW columns)
+    constexpr int NV = R / RP;                         // tile elements per thread
+    static_assert(RP >= 1 && RP * CW == NW * 64 && R % (2 * RP) == 0 && NV == 16, "tile fill: CW threads per row");
+    extern __shared__ double tl[];                     // [chunk][R + 2]
+    constexpr int LD = R + 2;
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t i0 = A.row_begin + (int64_t)blockIdx.x * R;
+    const int ib = (int)(blockIdx.x % (unsigned)A.nib), kg = (int)(blockIdx.x / (unsigned)A.nib);
+    const int64_t i0 = A.row_begin + (int64_t)ib * R;
     const int nr = (A.row_end - i0) < R ? (int)(A.row_end - i0) : R;
-    const int first_slice = A.full ? 0 : (int)(i0 / WAVE);     // slices left of the diagonal hold nothing
+    const int sl = kg * NW + wave;                     // this wave's 64 rows of H
+    const int64_t k = (int64_t)sl * WAVE + lane;
+    const bool kin = k < A.n;
+    double *crow = A.C + (int64_t)(i0 - A.row_begin) * A.ldc + k;
+    // the whole k-group lies left of the diagonal: the reference's calloc'd zeros
+    if (!A.full && (int64_t)(kg + 1) * NW * WAVE <= i0) {
+        if (kin)
+            for (int r = 0; r < nr; ++r) crow[(int64_t)r * A.ldc] = 0.0;
+        return;
+    }
+    const bool work = sl < A.nslices && (A.full || (int64_t)(sl + 1) * WAVE > i0);
+    double sum[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) sum[r] = 0.0;
+    // Tile fill: thread (fr, fx) owns column fx of tile rows fr, fr + RP, ...  The NV elements of the
+    // NEXT chunk travel in registers while the current chunk is consumed: two of the loads are issued
+    // with each of the first NV/2 step pairs, next to the H entries requested there, so they complete
+    // together (vmcnt retires in order: a block of tile loads in front of the step loop would stall
+    // the first wait for H entries for a full memory round trip; a fill between the two barriers
+    // cost 15 % of the kernel).  Rows past the last row of the block and columns past the chunk are
+    // clamped (loaded twice, stored never / never read).
+    const int fx = threadIdx.x % CW, fr = threadIdx.x / CW;
+    const double *trow[1];
+    trow[0] = A.T + (i0 - A.row_begin) * A.K;
+    double v[NV];
+#define TILE_LD(t, lo_, w_)                                                                     \
+    v[t] = trow[0][(int64_t)((fr + RP * (t)) < nr ? (fr + RP * (t)) : nr - 1) * A.K + (lo_) +   \
+                   (fx < (w_) ? fx : (w_) - 1)]
+    {
+        const int w0 = A.K < A.chunk ? A.K : A.chunk;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) TILE_LD(t, 0, w0);
+    }
+    // Per-chunk metadata (segment length of this lane's row, the slice's block in the ELL arrays) is
+    // loaded one chunk ahead, and the first two steps of a chunk are requested before the barrier,
+    // so no wave starts a chunk with a chain of dependent round trips.  Waves without work (slice
+    // beyond n or left of the diagonal) run the same loads on clamped indices and 0 steps.
+    const int slc = sl < A.nslices ? sl : A.nslices - 1;
+    const int64_t kc = kin ? k : A.n - 1;
+    int len_n = A.len[kc];
+    int64_t base_n = A.off[slc], end_n = A.off[slc + 1];
     for (int q = 0; q < A.nchunks; ++q) {
         const int lo = q * A.chunk;
         const int w = (A.K - lo) < A.chunk ? (A.K - lo) : A.chunk;
-        __syncthreads();
-        for (int r = 0; r < R; ++r) {
-            const double *src = A.T + (int64_t)(i0 - A.row_begin + (r < nr ? r : nr - 1)) * A.K + lo;
-            for (int x = threadIdx.x; x < w; x += NW * 64) tl[r * A.chunk + x] = src[x];
+        const int len = (work && kin) ? len_n : 0;
+        const int steps = work ? (int)((end_n - base_n) / WAVE) : 0;
+        const short *cp = A.col + base_n + lane;
+        const double *vp = A.val + base_n + lane;
+        // the entries of the next two steps are in flight while two steps are consumed (indices are
+        // clamped into the slice's block; a clamped step has st >= steps >= len and adds nothing)
+        const int last = steps > 0 ? steps - 1 : 0;
+        const int s1 = 1 < last ? 1 : last;
+        int c0 = cp[0], c1 = cp[(int64_t)s1 * WAVE];
+        double h0 = vp[0], h1 = vp[(int64_t)s1 * WAVE];
+        __syncthreads();                               // nobody reads the previous tile any more
+        if (fx < w) {
+            double *dst = tl + fx * LD + fr;
+#pragma unroll
+            for (int t = 0; t < NV; ++t) dst[RP * t] = v[t];
         }
+        const int qn = q + 1 < A.nchunks ? q + 1 : q;
+        len_n = A.len[(size_t)qn * A.n + kc];
+        base_n = A.off[(size_t)qn * A.nslices + slc];
+        end_n = A.off[(size_t)qn * A.nslices + slc + 1];
+        const int lon = qn * A.chunk;
+        const int wn = (A.K - lon) < A.chunk ? (A.K - lon) : A.chunk;
         __syncthreads();
-        for (int sl = first_slice + wave; sl < A.nslices; sl += NW) {
-            const int64_t k = (int64_t)sl * WAVE + lane;
-            const bool kin = k < A.n;
-            const int len = kin ? A.len[(size_t)q * A.n + k] : 0;
-            const int64_t base = A.off[(size_t)q * A.nslices + sl];
-            const int steps = (int)((A.off[(size_t)q * A.nslices + sl + 1] - base) / WAVE);
-            double sum[R];
-            bool mine[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                mine[r] = kin && r < nr && (A.full || k >= i0 + r);
-                sum[r] = 0.0;
-                if (q > 0 && mine[r]) sum[r] = A.C[(int64_t)(i0 - A.row_begin + r) * A.ldc + k];
-            }
-            const short *cp = A.col + base + lane;
-            const double *vp = A.val + base + lane;
-#pragma unroll 4
-            for (int st = 0; st < steps; ++st) {
-                const int c = cp[(int64_t)st * WAVE];
-                const double hv = vp[(int64_t)st * WAVE];
-                if (st < len) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) sum[r] += tl[r * A.chunk + c] * hv;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (mine[r]) A.C[(int64_t)(i0 - A.row_begin + r) * A.ldc + k] = sum[r];
+        int st = 0;
+#define STEP_PAIR()                                                                             \
+        {                                                                                       \
+            const int s2 = st + 2 < last ? st + 2 : last, s3 = st + 3 < last ? st + 3 : last;   \
+            const int n0 = cp[(int64_t)s2 * WAVE], n1 = cp[(int64_t)s3 * WAVE];                 \
+            const double g0 = vp[(int64_t)s2 * WAVE], g1 = vp[(int64_t)s3 * WAVE];              \
+            if (st < len) {                                                                     \
+                const double2 *p = reinterpret_cast<const double2 *>(tl + c0 * LD);             \
+                _Pragma("unroll") for (int r = 0; r < R; r += 2) {                              \
+                    const double2 x = p[r >> 1];                                                \
+                    sum[r] += x.x * h0;                                                         \
+                    sum[r + 1] += x.y * h0;                                                     \
+                }                                                                               \
+            }                                                                                   \
+            if (st + 1 < len) {                                                                 \
+                const double2 *p = reinterpret_cast<const double2 *>(tl + c1 * LD);             \
+                _Pragma("unroll") for (int r = 0; r < R; r += 2) {                              \
+                    const double2 x = p[r >> 1];                                                \
+                    sum[r] += x.x * h1;                                                         \
+                    sum[r + 1] += x.y * h1;                                                     \
+                }                                                                               \
+            }                                                                                   \
+            c0 = n0; c1 = n1; h0 = g0; h1 = g1;                                                 \
+            st += 2;                                                                            \
         }
+#define FILL_PAIR(t) TILE_LD(2 * (t), lon, wn); TILE_LD(2 * (t) + 1, lon, wn); STEP_PAIR()
+        FILL_PAIR(0) FILL_PAIR(1) FILL_PAIR(2) FILL_PAIR(3) FILL_PAIR(4) FILL_PAIR(5) FILL_PAIR(6) FILL_PAIR(7)
+        while (st < steps) STEP_PAIR()
+#undef FILL_PAIR
+#undef STEP_PAIR
     }
-    // cells left of the diagonal: the reference's calloc'd zeros
-    if (!A.full) {
-        for (int r = 0; r < nr; ++r) {
-            double *dst = A.C + (int64_t)(i0 - A.row_begin + r) * A.ldc;
-            for (int64_t k = threadIdx.x; k < i0 + r && k < A.n; k += NW * 64) dst[k] = 0.0;
-        }
+#undef TILE_LD
+    if (kin) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (r < nr) crow[(int64_t)r * A.ldc] = (A.full || k >= i0 + r) ? sum[r] : 0.0;
     }
 }
 

@@ -249,3 +249,20 @@ def test_legacy_zero_operand_and_mismatch(legacy):
     d = DArray()
     legacy.dense_nosym(ctypes.byref(b), ctypes.byref(b), ctypes.byref(d))           # 3x4 times 3x4: incompatible
     assert not d.array
+
+
+def test_legacy_symbols_honour_smm_exact(legacy, oracle, monkeypatch):
+    """SMM_EXACT=1 in the environment: the legacy symbols return the CPU loop's values bit for bit."""
+    monkeypatch.setenv("SMM_EXACT", "1")
+    A, B = rand_csr(300, 250, 0.2, 17), rand_csr(250, 300, 0.2, 18)
+    a, b, out, d = _to_sparsemat(legacy, A), _to_sparsemat(legacy, B), SparseMat(), DArray()
+    legacy.sparse_nosym(ctypes.byref(a), ctypes.byref(b), ctypes.byref(out), 5)
+    ptr, idx, val = _from_sparsemat(out)
+    want = oracle.sparse(arrays(A), arrays(B), 300)
+    assert np.array_equal(ptr, want[0]) and np.array_equal(idx, want[1]) and np.array_equal(val, want[2])
+    legacy.dense_sym(ctypes.byref(a), ctypes.byref(b), ctypes.byref(d))
+    got = np.ctypeslib.as_array(d.array, shape=(d.rows, d.cols)).copy()
+    assert np.array_equal(got, oracle.dense(arrays(A), arrays(B), 300, symmetric=True))
+    legacy.destroy_darray(ctypes.byref(d)); legacy.destroy_sparsemat(ctypes.byref(out))
+    for s in (a, b):
+        legacy.destroy_sparsemat(ctypes.byref(s))

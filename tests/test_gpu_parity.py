@@ -184,7 +184,8 @@ def test_dense_unsorted_b(ctx, oracle):
 
 
 @pytest.mark.parametrize("n,k,dh,dq", [(1, 1, 1.0, 1.0), (60, 90, 0.1, 0.1), (500, 500, 0.3, 0.3),
-                                       (300, 9000, 0.02, 0.004), (257, 5000, 0.05, 0.01)])
+                                       (300, 9000, 0.02, 0.004), (257, 5000, 0.05, 0.01),
+                                       (1500, 2500, 0.02, 0.004)])      # two k-groups of 1024 rows, three column chunks
 @pytest.mark.parametrize("full", [0, 1])
 @pytest.mark.parametrize("exact", MODES)
 def test_triple_matches_oracle(ctx, oracle, n, k, dh, dq, full, exact):
@@ -213,6 +214,18 @@ def test_triple_row_range(ctx, oracle):
     finally:
         h.close(); q.close()
     assert np.array_equal(np.vstack([top, bot]), want)
+
+
+def test_triple_row_range_across_k_groups(ctx, oracle):
+    """Row ranges that start inside a 16-row block and end past the first 1024-row k-group."""
+    H = rand_csr(1300, 1100, 0.02, 25); S = rand_csr(1100, 1100, 0.004, 26); Q = (S + S.T).tocsr()
+    want = oracle.triple(arrays(H), arrays(Q), 1100, full=0)
+    h, q = ctx.csr_from_scipy(H), ctx.csr_from_scipy(Q)
+    try:
+        parts = [ctx.triple_host(h, q, row_begin=r0, row_end=r1, exact=True) for r0, r1 in ((0, 1003), (1003, 1030), (1030, 1300))]
+    finally:
+        h.close(); q.close()
+    assert np.array_equal(np.vstack(parts), want)
 
 
 def test_row_shards_concatenate_to_single_result(ctx, oracle):
