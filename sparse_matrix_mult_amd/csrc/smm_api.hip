@@ -609,13 +609,12 @@ extern "C" int64_t smm_plan_nnz(const smm_plan *p) { return p ? p->nnz : -1; }
 template <bool SYM, bool SAFE, bool LDSBM>
 static int launch_symbolic_t(smm_ctx *c, smm_plan *p, int bm_words, unsigned *gbm, int grid, int wpb)
 {
-    const size_t lds = LDSBM ? (size_t)bm_words * wpb * sizeof(unsigned) : 0;
+    const size_t lds = LDSBM ? (size_t)(bm_words + 1) * wpb * sizeof(unsigned) : 0;     // + guard word per wave
     auto kern = smm_symbolic<SYM, SAFE, LDSBM>;
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     LAUNCH(c, "smm_symbolic", kern, grid, wpb * 64, lds, (int)p->m, p->row_offset, bm_words, p->a->ptr, p->a->idx,
-           p->b->ptr, p->b->idx, p->d_ub_off, p->d_tmp, p->d_P, p->d_rowcnt, gbm,
-           (const int *)((const char *)c->d_flags + 64));
+           p->b->ptr, p->b->idx, p->d_ub_off, p->d_tmp, p->d_P, p->d_rowcnt, gbm);
     LAUNCH_CHECK();
     return SMM_OK;
 }
@@ -670,7 +669,7 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     // symbolic: one wave per row.  The marker bitmap (ncols/8 bytes per wave) lives in LDS; waves per
     // workgroup are chosen so that as many waves as possible fit a CU's 160 KB
     const int bm_words = (int)((p->ncols + 31) / 32);
-    const size_t bm_bytes = (size_t)bm_words * sizeof(unsigned);
+    const size_t bm_bytes = (size_t)(bm_words + 1) * sizeof(unsigned);      // + the guard word
     const bool ldsbm = bm_bytes <= 128 * 1024;
     const bool safe = (b->vflags & (CSR_HAS_EQUAL | CSR_UNSORTED)) != 0;
     int wpb = 4;
@@ -683,7 +682,7 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     }
     int sgrid = (int)std::min<int64_t>((m + wpb - 1) / wpb, (int64_t)c->n_cu * 8 * (4 / wpb));
     unsigned *gbm = nullptr;
-    if (!ldsbm) PCHK(pool_get(c, (size_t)sgrid * wpb * bm_words, &gbm));
+    if (!ldsbm) PCHK(pool_get(c, (size_t)sgrid * wpb * (bm_words + 1), &gbm));
 #define SYM_CASE(S, F, L) if (sym == S && safe == F && ldsbm == L) PCHK((launch_symbolic_t<S, F, L>(c, p, bm_words, gbm, sgrid, wpb)));
     SYM_CASE(false, false, true) SYM_CASE(false, true, true) SYM_CASE(true, false, true) SYM_CASE(true, true, true)
     SYM_CASE(false, false, false) SYM_CASE(false, true, false) SYM_CASE(true, false, false) SYM_CASE(true, true, false)

@@ -53,6 +53,35 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// Load idx[lane] into v for the lanes of `mask` (uniform), whose other lanes keep their value: EXEC is
+// narrowed around one global_load with a scalar base and the constant per-lane offset 4*lane, so the
+// address costs no vector instruction and idle lanes issue no request.  Must be called with all 64
+// lanes active (EXEC is restored to -1).  The compiler does not see the load: the caller waits
+// with wait_vm() before it reads v.  (An `if (lane < cnt)` around an ordinary load made hipcc
+// branch around it and wait for vmcnt(0) at every join; a select between the real and a dummy
+// address cost 8 vector instructions per load.)
+__device__ __forceinline__ void load_masked(int &v, const int *idx, unsigned long long mask, int lane4) {
+    asm volatile("s_mov_b64 exec, %3\n\t"
+                 "global_load_dword %0, %1, %2\n\t"
+                 "s_mov_b64 exec, -1"
+                 : "+v"(v)
+                 : "v"(lane4), "s"(idx), "s"(mask));
+}
+// n is a constant after unrolling; the switch folds to one s_waitcnt
+__device__ __forceinline__ void wait_vm(int &v, int n) {
+#define SMM_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(v)); break;
+    switch (n) {
+        SMM_W(0) SMM_W(1) SMM_W(2) SMM_W(3) SMM_W(4) SMM_W(5) SMM_W(6) SMM_W(7)
+        SMM_W(8) SMM_W(9) SMM_W(10) SMM_W(11) SMM_W(12) SMM_W(13) SMM_W(14) SMM_W(15)
+    }
+#undef SMM_W
+}
+__device__ __forceinline__ void wait_vm_all(int (&v)[16]) {
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                   "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+}
+
 __device__ __forceinline__ void lds_add(double *p, double x) {
     // ds_add_f64 (no return): fire-and-forget, executed by the LDS in issue order
     (void)__hip_atomic_fetch_add(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -200,14 +229,15 @@ __global__ __launch_bounds__(1024) void smm_scan(int n, const T *__restrict__ in
 //   rowcnt[row]           : final length = nnz of the row of C
 // SAFE resolves two lanes of one wave-instruction hitting the same column (possible only
 // when a row of B repeats a column): the LOWEST lane must win, whatever the LDS picks.
-// The walk is over 64-lane CHUNKS of B's rows: a scalar cursor (entry j, position kb) steps
-// through the rows of 64 A entries; SYM_UNROLL chunk loads are issued together
-// (unconditional: idle lanes read a dummy -1) and then consumed strictly in order.  The B-row
-// pointers of the next 64 entries and the A indices of the 64 after those are prefetched.
-#ifndef SMM_SYM_UNROLL
-#define SMM_SYM_UNROLL 16
-#endif
-constexpr int SYM_UNROLL = SMM_SYM_UNROLL;
+// The walk is over 64-lane CHUNKS of B's rows.  The kernel is bound by instruction issue (one
+// scalar and one vector instruction per cycle and CU), not by bytes, so the per-chunk work is kept
+// minimal: for the rows of 64 A entries the chunk list is built with vector code (scan of the
+// chunk counts, one descriptor per lane: start offset + lane mask), 64 chunks at a time; the hot
+// loop reads a descriptor with three readlanes, issues SYM_UNROLL EXEC-masked loads together (idle
+// lanes keep the guard column and issue no request), then all test-and-sets, then consumes them
+// strictly in order.  The B-row pointers of the next 64 entries and the A indices of the 64 after
+// those are prefetched.
+constexpr int SYM_UNROLL = 16;        // chunk loads in flight per wave (8 and 32 measured slower); wait_vm_all is written for 16
 template <bool SYM, bool SAFE, bool LDSBM>
 __global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, int bm_words,
                                                     const int *__restrict__ a_ptr,
@@ -218,16 +248,20 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, i
                                                     int *__restrict__ tmp_idx,
                                                     unsigned *__restrict__ P,
                                                     int *__restrict__ rowcnt,
-                                                    unsigned *__restrict__ gbitmap,
-                                                    const int *__restrict__ dummy_idx)
+                                                    unsigned *__restrict__ gbitmap)
 {
     extern __shared__ unsigned lds_bm[];
     const int lane = lane_id();
+    const int lane4 = lane * 4;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wpb = blockDim.x / WAVE;
-    unsigned *bm = LDSBM ? lds_bm + (size_t)wave * bm_words
-                         : gbitmap + ((size_t)blockIdx.x * wpb + wave) * bm_words;
+    // one guard word behind each wave's bitmap, all ones: idle lanes carry the column `idle` = bit 31
+    // of that word, which is therefore never "new" -- no per-lane predicate in the hot loop
+    unsigned *bm = LDSBM ? lds_bm + (size_t)wave * (bm_words + 1)
+                         : gbitmap + ((size_t)blockIdx.x * wpb + wave) * (bm_words + 1);
+    const int idle = bm_words * 32 + 31;
     for (int w = lane; w < bm_words; w += WAVE) bm[w] = 0;
+    if (lane == 0) bm[bm_words] = 0xffffffffu;
     if (!LDSBM) __threadfence();
 
     for (int row = blockIdx.x * wpb + wave; row < m; row += gridDim.x * wpb) {
@@ -246,69 +280,92 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, i
                 const int bs_n = b_ptr[r_n], be_n = b_ptr[r_n + 1];      // next 64 entries' rows of B
                 const int r_nn = load_r(jb + 2 * WAVE);                    // A indices two batches ahead
                 unsigned myP = 0xffffffffu;                             // unset: entry without chunks
-                // chunk cursor of this batch: the next chunk to issue is [kb, kb+64) of entry j
-                // (kb < en while j < nb); `fresh` = it is the first chunk of that entry
-                int j = -1, kb = 0, en = 0;
-                bool fresh = true;
-                auto advance = [&]() {                                  // next entry with a non-empty row of B
-                    do {
-                        ++j;
-                        if (j >= nb) break;
-                        kb = rl(bs, j);
-                        en = rl(be, j);
-                    } while (kb >= en);
-                    fresh = true;
-                };
-                advance();
-                while (j < nb) {
-                    int c[SYM_UNROLL], owner[SYM_UNROLL];
+                // Re-define bs/be here so that the compiler's wait for their loads sits HERE, once: a
+                // vmcnt wait inside the chunk loop would also drain the chunk loads of load_masked
+                // (vmcnt retires in order).
+                asm volatile("" : "+v"(bs), "+v"(be));
+                // entry `lane` of the batch owns the chunks [excl, incl) of the batch's chunk list
+                const int nch = lane < nb ? (be - bs + WAVE - 1) >> 6 : 0;
+                int incl = nch;
 #pragma unroll
-                    for (int u = 0; u < SYM_UNROLL; ++u) {              // all loads first (MLP)
-                        const bool live = j < nb;                       // wave-uniform
-                        const int k = kb + lane;
-                        const bool p = live && k < en;
-                        const int *ip = p ? b_idx + k : dummy_idx;
-                        c[u] = *ip;
-                        owner[u] = (live && fresh) ? j : -1;            // first chunk of entry j
-                        fresh = false;
-                        kb += WAVE;
-                        if (live && kb >= en) advance();
-                    }
-                    // test-and-set every chunk's columns (LDS atomics of one wave execute in issue
-                    // order, so chunk u sees the bits of chunks < u whenever its result is read);
-                    // idle lanes OR a zero into word 0.  All 16 atomics are issued before the first
-                    // result is consumed: one LDS round trip per round instead of one per chunk.
-                    unsigned old[SYM_UNROLL], bit[SYM_UNROLL], pre[SYM_UNROLL];
+                for (int o = 1; o < WAVE; o <<= 1) {
+                    const int y = __shfl_up(incl, o);
+                    if (lane >= o) incl += y;
+                }
+                const int excl = incl - nch;
+                const int T = rl(incl, WAVE - 1);
+                for (int tg = 0; tg < T; tg += WAVE) {
+                    // descriptor of chunk t = tg + lane: its entry is the number of entries whose chunks
+                    // all precede t (binary search over the scan), then start offset and lane mask
+                    const int t = tg + lane;
+                    int ej = 0;
 #pragma unroll
-                    for (int u = 0; u < SYM_UNROLL; ++u) {
-                        const bool a = c[u] >= thresh;                  // also drops the dummy -1
-                        bit[u] = a ? 1u << (c[u] & 31) : 0u;
-                        unsigned *wp = bm + (a ? (c[u] >> 5) : 0);
-                        if (SAFE) pre[u] = *(volatile unsigned *)wp;
-                        old[u] = atomicOr(wp, bit[u]);
-                    }
+                    for (int sft = WAVE / 2; sft > 0; sft >>= 1)
+                        if (__shfl(incl, ej + sft - 1) <= t) ej += sft;
+                    const int start = __shfl(bs, ej) + (t - __shfl(excl, ej)) * WAVE;
+                    const int cnt = __shfl(be, ej) - start;             // >= 1 for t < T
+                    const unsigned long long lm = t >= T ? 0ull : cnt >= WAVE ? ~0ull : (1ull << cnt) - 1ull;
+                    const unsigned d_off = t < T ? (unsigned)start : 0u, d_lo = (unsigned)lm, d_hi = (unsigned)(lm >> 32);
+                    const int G = T - tg < WAVE ? T - tg : WAVE;
+                    int nrec = 0;                                       // lane t: length of the list before chunk t
+                    for (int rb = 0; rb < G; rb += SYM_UNROLL) {
+                        int c[SYM_UNROLL];
 #pragma unroll
-                    for (int u = 0; u < SYM_UNROLL; ++u) {              // then consume in order
-                        if (lane == owner[u]) myP = (unsigned)n;
-                        bool isnew = (bit[u] & ~old[u]) != 0;
-                        if (SAFE) {
-                            // two lanes of this instruction with the same new column: the LOWEST wins
-                            const bool a = bit[u] != 0;
-                            unsigned long long losers = __ballot(a && !(pre[u] & bit[u]) && !isnew);
-                            while (losers) {                     // rare: duplicate column in a B row
-                                const int x = __ffsll((long long)losers) - 1;
-                                const int cx = rl(c[u], x);
-                                const bool ingrp = a && c[u] == cx;
-                                const unsigned long long grp = __ballot(ingrp);
-                                const int firstl = __ffsll((long long)grp) - 1;
-                                if (ingrp) isnew = (lane == firstl);
-                                losers &= ~grp;
-                            }
+                        for (int u = 0; u < SYM_UNROLL; ++u) c[u] = idle;       // idle lanes / dead slots
+#pragma unroll
+                        for (int u = 0; u < SYM_UNROLL; ++u) {                  // all loads first (MLP)
+                            const int tt = rb + u;
+                            const unsigned long long mk = ((unsigned long long)rl(d_hi, tt) << 32) | rl(d_lo, tt);
+                            load_masked(c[u], b_idx + rl(d_off, tt), mk, lane4);
                         }
-                        const unsigned long long mask = __ballot(isnew);
-                        if (isnew) out[n + mbcnt(mask)] = c[u];
-                        n += __popcll(mask);
+                        // chunk u of a full round has SYM_UNROLL-1-u younger loads behind it; in a partial
+                        // round the dead slots may not count at all (EXEC = 0), so it simply drains
+                        if (rb + SYM_UNROLL > G) wait_vm_all(c);
+                        // test-and-set every chunk's columns (LDS atomics of one wave execute in issue
+                        // order, so chunk u sees the bits of chunks < u whenever its result is read).  All
+                        // 16 atomics are issued before the first result is consumed: one LDS round trip
+                        // per round instead of one per chunk.
+                        unsigned old[SYM_UNROLL], bit[SYM_UNROLL], pre[SYM_UNROLL];
+#pragma unroll
+                        for (int u = 0; u < SYM_UNROLL; ++u) {
+                            wait_vm(c[u], SYM_UNROLL - 1 - u);
+                            if (SYM) c[u] = c[u] >= thresh ? c[u] : idle;   // left of the diagonal: as idle
+                            bit[u] = 1u << (c[u] & 31);
+                            unsigned *wp = bm + (c[u] >> 5);                // idle -> the guard word
+                            if (SAFE) pre[u] = *(volatile unsigned *)wp;
+                            old[u] = atomicOr(wp, bit[u]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);                  // no result is consumed between the atomics
+#pragma unroll
+                        for (int u = 0; u < SYM_UNROLL; ++u) {              // then consume in order
+                            if (lane == rb + u) nrec = n;
+                            bool isnew = (bit[u] & ~old[u]) != 0;
+                            if (SAFE) {
+                                // two lanes of this instruction with the same new column: the LOWEST wins
+                                const bool a = c[u] != idle;
+                                unsigned long long losers = __ballot(a && !(pre[u] & bit[u]) && !isnew);
+                                while (losers) {                     // rare: duplicate column in a B row
+                                    const int x = __ffsll((long long)losers) - 1;
+                                    const int cx = rl(c[u], x);
+                                    const bool ingrp = a && c[u] == cx;
+                                    const unsigned long long grp = __ballot(ingrp);
+                                    const int firstl = __ffsll((long long)grp) - 1;
+                                    if (ingrp) isnew = (lane == firstl);
+                                    losers &= ~grp;
+                                }
+                            }
+                            const unsigned long long mask = __ballot(isnew);
+                            if (isnew)
+                                out[__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)n))] = c[u];
+                            n += __popcll(mask);
+                        }
                     }
+                    // P of the entries whose first chunk was in this group
+                    const int tl = excl - tg;
+                    const bool has = nch > 0 && tl >= 0 && tl < G;
+                    const int pv = __shfl(nrec, has ? tl : 0);
+                    if (has) myP = (unsigned)pv;
                 }
                 // an entry whose row of B is empty starts where the next one starts
                 {
