@@ -606,15 +606,39 @@ extern "C" void smm_plan_destroy(smm_plan *p)
 }
 extern "C" int64_t smm_plan_nnz(const smm_plan *p) { return p ? p->nnz : -1; }
 
-template <bool SYM, bool SAFE, bool LDSBM>
-static int launch_symbolic_t(smm_ctx *c, smm_plan *p, int bm_words, unsigned *gbm, int grid, int wpb)
+// exclusive scan of n values into out[0..n] (out[n] = total)
+template <typename T>
+static int scan_launch(smm_ctx *c, int64_t n, const T *in, int64_t *out)
 {
-    const size_t lds = LDSBM ? (size_t)(bm_words + 1) * wpb * sizeof(unsigned) : 0;     // + guard word per wave
-    auto kern = smm_symbolic<SYM, SAFE, LDSBM>;
+    if (n <= 8 * SCAN_TILE) {
+        LAUNCH(c, "smm_scan", smm_scan<T>, 1, 1024, 0, (int)n, in, out);
+        LAUNCH_CHECK();
+        return SMM_OK;
+    }
+    const int tiles = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
+    int64_t *sums = nullptr;
+    CHK(pool_get(c, (size_t)2 * tiles + 1, &sums));
+    LAUNCH(c, "smm_scan", smm_scan_tile_sums<T>, tiles, 1024, 0, (int)n, in, sums);
+    LAUNCH(c, "smm_scan", smm_scan<int64_t>, 1, 1024, 0, tiles, (const int64_t *)sums, sums + tiles);
+    LAUNCH(c, "smm_scan", smm_scan_tiles<T>, tiles, 1024, 0, (int)n, in, (const int64_t *)(sums + tiles), out);
+    hipError_t e = hipGetLastError();
+    pool_free(c, sums);         // stream-ordered reuse: the pool hands it out again only to work queued behind these launches
+    if (e != hipSuccess) return fail(SMM_ERR_HIP, "scan: %s", hipGetErrorString(e));
+    return SMM_OK;
+}
+
+template <bool SYM, bool SAFE, int MARK>
+static int launch_symbolic_t(smm_ctx *c, smm_plan *p, int words, unsigned *gbm, int grid, int wpb, const int *rowlist,
+                             const int *d_nrows)
+{
+    // LDS per wave: bitmap words + the guard word, or the hash slots
+    const size_t lds = MARK == MARK_GLOBAL_BITMAP ? 0 : (size_t)(words + (MARK == MARK_LDS_HASH ? 0 : 1)) * wpb * sizeof(unsigned);
+    auto kern = smm_symbolic<SYM, SAFE, MARK>;
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    LAUNCH(c, "smm_symbolic", kern, grid, wpb * 64, lds, (int)p->m, p->row_offset, bm_words, p->a->ptr, p->a->idx,
-           p->b->ptr, p->b->idx, p->d_ub_off, p->d_tmp, p->d_P, p->d_rowcnt, gbm);
+    LAUNCH(c, MARK == MARK_LDS_HASH ? "smm_symbolic_hash" : "smm_symbolic", kern, grid, wpb * 64, lds, (int)p->m, rowlist,
+           d_nrows, p->row_offset, words, p->a->ptr, p->a->idx, p->b->ptr, p->b->idx, p->d_ub_off, p->d_tmp, p->d_P,
+           p->d_rowcnt, gbm);
     LAUNCH_CHECK();
     return SMM_OK;
 }
@@ -654,10 +678,33 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     const int wgrid = (int)std::min<int64_t>((m + 3) / 4, 16384);
     LAUNCH(c, "smm_row_work", smm_row_work, wgrid, 256, 0, (int)m, (int)p->ncols, p->row_offset, sym ? 1 : 0, a->ptr,
            a->idx, b->ptr, d_prod, d_ub);
-    LAUNCH(c, "smm_scan", smm_scan<int64_t>, 1, 1024, 0, (int)m, (const int64_t *)d_ub, p->d_ub_off);
+    PCHK(scan_launch<int64_t>(c, m, d_ub, p->d_ub_off));
+    // The marker of the symbolic phase is a bitmap of B's columns (ncols/8 bytes per wave, in LDS when
+    // it fits): at 50 000 columns 24 waves fit a CU, at 1e6 columns one.  Rows with few products --
+    // known now -- therefore take an LDS hash set instead, wherever that is the smaller marker:
+    //   class 0: <= 256 products, 512 slots (2 KB per wave); class 1: <= 2048 products, 4096 slots (16 KB).
+    const int bm_words = (int)((p->ncols + 31) / 32);
+    const size_t bm_bytes = (size_t)(bm_words + 1) * sizeof(unsigned);      // + the guard word
+    const bool ldsbm = bm_bytes <= 128 * 1024;
+    const bool safe = (b->vflags & (CSR_HAS_EQUAL | CSR_UNSORTED)) != 0;
+    constexpr int HS0 = 512, HS1 = 4096;
+    const int hmax0 = (!safe && bm_bytes > HS0 * 4) ? HS0 / 2 : 0;
+    const int hmax1 = (!safe && bm_bytes > HS1 * 4) ? HS1 / 2 : hmax0;
+    int sbin[3] = {0, 0, (int)m};
+    int *d_slists = nullptr;
+    int *d_scounts = (int *)((char *)c->d_flags + 224);
+    if (hmax1 > 0) {
+        PCHK(pool_get(c, (size_t)3 * m, &d_slists));
+        hipError_t e = hipMemsetAsync(d_scounts, 0, 3 * sizeof(int), c->stream);
+        if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "memset: %s", hipGetErrorString(e)); }
+        LAUNCH(c, "smm_bin_rows", smm_bin_rows<int64_t>, std::min<int64_t>((m + 255) / 256, 4096), 256, 0, (int)m, hmax0, hmax1,
+               (const int64_t *)d_ub, d_slists, d_scounts);
+    }
     int64_t total_ub = 0;
     {
         hipError_t e = hipMemcpyAsync(&total_ub, p->d_ub_off + m, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && hmax1 > 0)
+            e = hipMemcpyAsync(sbin, d_scounts, 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "row work: %s", hipGetErrorString(e)); }
     }
@@ -665,13 +712,24 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     PCHK(pool_get(c, (size_t)std::max<int64_t>(total_ub, 1), &p->d_tmp));
     PCHK(pool_get(c, (size_t)a->nnz, &p->d_P));
     PCHK(pool_get(c, (size_t)m, &p->d_rowcnt));
+    if (hmax1 > 0) {            // rows without products are in no bin: their count stays 0
+        hipError_t e = hipMemsetAsync(p->d_rowcnt, 0, (size_t)m * sizeof(int), c->stream);
+        if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "memset: %s", hipGetErrorString(e)); }
+    }
 
-    // symbolic: one wave per row.  The marker bitmap (ncols/8 bytes per wave) lives in LDS; waves per
-    // workgroup are chosen so that as many waves as possible fit a CU's 160 KB
-    const int bm_words = (int)((p->ncols + 31) / 32);
-    const size_t bm_bytes = (size_t)(bm_words + 1) * sizeof(unsigned);      // + the guard word
-    const bool ldsbm = bm_bytes <= 128 * 1024;
-    const bool safe = (b->vflags & (CSR_HAS_EQUAL | CSR_UNSORTED)) != 0;
+    // hash classes: one wave per row, four rows per workgroup
+    for (int cls = 0; cls < 2; ++cls) {
+        if (hmax1 == 0 || sbin[cls] == 0) continue;
+        const int hs = cls == 0 ? HS0 : HS1;
+        const int hgrid = (int)std::min<int64_t>((sbin[cls] + 3) / 4, (int64_t)c->n_cu * 16);
+        if (sym) PCHK((launch_symbolic_t<true, false, MARK_LDS_HASH>(c, p, hs, nullptr, hgrid, 4, d_slists + (size_t)cls * m, d_scounts + cls)));
+        else     PCHK((launch_symbolic_t<false, false, MARK_LDS_HASH>(c, p, hs, nullptr, hgrid, 4, d_slists + (size_t)cls * m, d_scounts + cls)));
+    }
+    // bitmap kernels for the rest: one wave per row; waves per workgroup are chosen so that as many
+    // waves as possible fit a CU's 160 KB
+    const int64_t nbm = hmax1 > 0 ? sbin[2] : m;
+    const int *bm_rows = hmax1 > 0 ? d_slists + (size_t)2 * m : nullptr;
+    const int *bm_count = hmax1 > 0 ? d_scounts + 2 : nullptr;
     int wpb = 4;
     if (ldsbm) {
         int best = 0;
@@ -680,14 +738,18 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
             if (waves > best) { best = waves; wpb = cand; }
         }
     }
-    int sgrid = (int)std::min<int64_t>((m + wpb - 1) / wpb, (int64_t)c->n_cu * 8 * (4 / wpb));
     unsigned *gbm = nullptr;
-    if (!ldsbm) PCHK(pool_get(c, (size_t)sgrid * wpb * (bm_words + 1), &gbm));
-#define SYM_CASE(S, F, L) if (sym == S && safe == F && ldsbm == L) PCHK((launch_symbolic_t<S, F, L>(c, p, bm_words, gbm, sgrid, wpb)));
-    SYM_CASE(false, false, true) SYM_CASE(false, true, true) SYM_CASE(true, false, true) SYM_CASE(true, true, true)
-    SYM_CASE(false, false, false) SYM_CASE(false, true, false) SYM_CASE(true, false, false) SYM_CASE(true, true, false)
+    if (nbm > 0) {
+        int sgrid = (int)std::min<int64_t>((nbm + wpb - 1) / wpb, (int64_t)c->n_cu * 8 * (4 / wpb));
+        if (!ldsbm) PCHK(pool_get(c, (size_t)sgrid * wpb * (bm_words + 1), &gbm));
+        const int mark = ldsbm ? MARK_LDS_BITMAP : MARK_GLOBAL_BITMAP;
+#define SYM_CASE(S, F, L) if (sym == S && safe == F && mark == L) PCHK((launch_symbolic_t<S, F, L>(c, p, bm_words, gbm, sgrid, wpb, bm_rows, bm_count)));
+        SYM_CASE(false, false, MARK_LDS_BITMAP) SYM_CASE(false, true, MARK_LDS_BITMAP) SYM_CASE(true, false, MARK_LDS_BITMAP)
+        SYM_CASE(true, true, MARK_LDS_BITMAP) SYM_CASE(false, false, MARK_GLOBAL_BITMAP) SYM_CASE(false, true, MARK_GLOBAL_BITMAP)
+        SYM_CASE(true, false, MARK_GLOBAL_BITMAP) SYM_CASE(true, true, MARK_GLOBAL_BITMAP)
 #undef SYM_CASE
-    LAUNCH(c, "smm_scan", smm_scan<int>, 1, 1024, 0, (int)m, (const int *)p->d_rowcnt, p->d_cptr);
+    }
+    PCHK(scan_launch<int>(c, m, p->d_rowcnt, p->d_cptr));
     {
         hipError_t e = hipMemcpyAsync(&p->nnz, p->d_cptr + m, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -695,12 +757,13 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "symbolic phase: %s", hipGetErrorString(e)); }
     }
     if (gbm) pool_free(c, gbm);
+    if (d_slists) pool_free(c, d_slists);
     if (p->nnz > 0) {
         // bin the rows of C: few nonzeros -> LDS hash kernels, the rest -> dense LDS tiles
         PCHK(pool_get(c, (size_t)3 * m, &p->d_lists));
         int *d_counts = (int *)((char *)c->d_flags + 192);
         hipError_t e = hipMemsetAsync(d_counts, 0, 3 * sizeof(int), c->stream);
-        LAUNCH(c, "smm_bin_rows", smm_bin_rows, std::min<int64_t>((m + 255) / 256, 4096), 256, 0, (int)m, c->hash_small,
+        LAUNCH(c, "smm_bin_rows", smm_bin_rows<int>, std::min<int64_t>((m + 255) / 256, 4096), 256, 0, (int)m, c->hash_small,
                c->hash_medium, (const int *)p->d_rowcnt, p->d_lists, d_counts);
         if (e == hipSuccess) e = hipMemcpyAsync(p->n_bin, d_counts, 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

@@ -219,6 +219,59 @@ __global__ __launch_bounds__(1024) void smm_scan(int n, const T *__restrict__ in
     if (threadIdx.x == 0) out[n] = carry_s;
 }
 
+// The same scan for long arrays (1e6 rows: the single workgroup above takes 1.5 ms), three launches:
+// sums of 4096-element tiles, the scan above over those sums, then every tile scans itself
+// on top of its offset.  tile_off has tiles+1 entries (the last one is the total).
+constexpr int SCAN_TILE = 4096;
+template <typename T>
+__global__ __launch_bounds__(1024) void smm_scan_tile_sums(int n, const T *__restrict__ in, int64_t *__restrict__ sums)
+{
+    __shared__ int64_t wsum[16];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int base = blockIdx.x * SCAN_TILE;
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_TILE / 1024; ++k) {
+        const int i = base + k * 1024 + threadIdx.x;
+        if (i < n) s += (int64_t)in[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if (lane == 0) wsum[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t t = 0;
+        for (int w = 0; w < 16; ++w) t += wsum[w];
+        sums[blockIdx.x] = t;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void smm_scan_tiles(int n, const T *__restrict__ in, const int64_t *__restrict__ tile_off,
+                                                       int64_t *__restrict__ out)
+{
+    __shared__ int64_t wsum[16];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int base = blockIdx.x * SCAN_TILE;
+    int64_t carry = tile_off[blockIdx.x];
+    for (int k = 0; k < SCAN_TILE / 1024; ++k) {
+        const int i = base + k * 1024 + threadIdx.x;
+        const int64_t v = i < n ? (int64_t)in[i] : 0;
+        int64_t x = v;                                   // inclusive wave scan
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const int64_t y = __shfl_up(x, o);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int64_t woff = 0, all = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wave) woff += wsum[w]; all += wsum[w]; }
+        if (i < n) out[i] = carry + woff + x - v;
+        carry += all;
+        __syncthreads();
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = tile_off[gridDim.x];
+}
+
 // ---------------------------------------------------------------------------------------
 // Symbolic phase = the reference's first-touch rule (sparsework.cpp:70-110 with the marker
 // of the working revision): walk A's row in stored order, inside it B's row in stored
@@ -238,8 +291,10 @@ __global__ __launch_bounds__(1024) void smm_scan(int n, const T *__restrict__ in
 // strictly in order.  The B-row pointers of the next 64 entries and the A indices of the 64 after
 // those are prefetched.
 constexpr int SYM_UNROLL = 16;        // chunk loads in flight per wave (8 and 32 measured slower); wait_vm_all is written for 16
-template <bool SYM, bool SAFE, bool LDSBM>
-__global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, int bm_words,
+enum { MARK_LDS_BITMAP = 0, MARK_GLOBAL_BITMAP = 1, MARK_LDS_HASH = 2 };
+template <bool SYM, bool SAFE, int MARK>
+__global__ __launch_bounds__(256) void smm_symbolic(int m, const int *__restrict__ rowlist,
+                                                    const int *__restrict__ nrows_p, int64_t row_offset, int bm_words,
                                                     const int *__restrict__ a_ptr,
                                                     const int *__restrict__ a_idx,
                                                     const int *__restrict__ b_ptr,
@@ -251,20 +306,31 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, i
                                                     unsigned *__restrict__ gbitmap)
 {
     extern __shared__ unsigned lds_bm[];
+    constexpr bool HASH = MARK == MARK_LDS_HASH;
+    static_assert(!(HASH && SAFE), "rows of B with repeated columns take the bitmap kernels");
     const int lane = lane_id();
     const int lane4 = lane * 4;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wpb = blockDim.x / WAVE;
-    // one guard word behind each wave's bitmap, all ones: idle lanes carry the column `idle` = bit 31
-    // of that word, which is therefore never "new" -- no per-lane predicate in the hot loop
-    unsigned *bm = LDSBM ? lds_bm + (size_t)wave * (bm_words + 1)
-                         : gbitmap + ((size_t)blockIdx.x * wpb + wave) * (bm_words + 1);
-    const int idle = bm_words * 32 + 31;
-    for (int w = lane; w < bm_words; w += WAVE) bm[w] = 0;
-    if (lane == 0) bm[bm_words] = 0xffffffffu;
-    if (!LDSBM) __threadfence();
+    const int nrows = nrows_p ? *nrows_p : m;
+    // Marker of the columns seen in the current row.
+    //  bitmaps: one guard word behind each wave's bitmap, all ones: idle lanes carry the column `idle` =
+    //           bit 31 of that word, which is therefore never "new" -- no per-lane predicate in the hot loop.
+    //  hash:    for rows with few products (known before this kernel runs) an open-addressing set of
+    //           `bm_words` slots (a power of two >= 2 x products) replaces the bitmap, whose ncols/8
+    //           bytes per wave leave one wave per CU at 1e6 columns; idle lanes carry -1.
+    unsigned *bm = MARK == MARK_GLOBAL_BITMAP ? gbitmap + ((size_t)blockIdx.x * wpb + wave) * (bm_words + 1)
+                                              : lds_bm + (size_t)wave * (bm_words + (HASH ? 0 : 1));
+    int *tab = (int *)bm;
+    const int idle = HASH ? -1 : bm_words * 32 + 31;
+    const unsigned hmask = (unsigned)bm_words - 1u;
+    const int hshift = __builtin_clz((unsigned)bm_words) + 1;
+    for (int w = lane; w < bm_words; w += WAVE) bm[w] = HASH ? 0xffffffffu : 0u;
+    if (!HASH && lane == 0) bm[bm_words] = 0xffffffffu;
+    if (MARK == MARK_GLOBAL_BITMAP) __threadfence();
 
-    for (int row = blockIdx.x * wpb + wave; row < m; row += gridDim.x * wpb) {
+    for (int ri = blockIdx.x * wpb + wave; ri < nrows; ri += gridDim.x * wpb) {
+        const int row = rowlist ? rowlist[ri] : ri;
         const int a0 = a_ptr[row], a1 = a_ptr[row + 1];
         int thresh = 0;
         if (SYM) { const int64_t gi = row + row_offset; thresh = gi > 0x7fffffff ? 0x7fffffff : (int)gi; }
@@ -321,6 +387,32 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, i
                         // chunk u of a full round has SYM_UNROLL-1-u younger loads behind it; in a partial
                         // round the dead slots may not count at all (EXEC = 0), so it simply drains
                         if (rb + SYM_UNROLL > G) wait_vm_all(c);
+                        if constexpr (HASH) {
+                            // chunk after chunk: look the columns up in the set, insert the unseen ones
+                            // (linear probing; the columns of one chunk are distinct, so two lanes
+                            // compete for a slot only with different keys and the loser moves on)
+#pragma unroll
+                            for (int u = 0; u < SYM_UNROLL; ++u) {
+                                wait_vm(c[u], SYM_UNROLL - 1 - u);
+                                if (SYM) c[u] = c[u] >= thresh ? c[u] : -1;
+                                if (lane == rb + u) nrec = n;
+                                bool pend = c[u] >= 0, isnew = false;
+                                unsigned h = ((unsigned)c[u] * 0x9E3779B1u) >> hshift;
+                                while (__ballot(pend)) {
+                                    if (pend) {
+                                        const int was = atomicCAS(&tab[h], -1, c[u]);
+                                        if (was == -1) { isnew = true; pend = false; }
+                                        else if (was == c[u]) pend = false;
+                                        else h = (h + 1) & hmask;
+                                    }
+                                }
+                                const unsigned long long mask = __ballot(isnew);
+                                if (isnew)
+                                    out[__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                  __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)n))] = c[u];
+                                n += __popcll(mask);
+                            }
+                        } else {
                         // test-and-set every chunk's columns (LDS atomics of one wave execute in issue
                         // order, so chunk u sees the bits of chunks < u whenever its result is read).  All
                         // 16 atomics are issued before the first result is consumed: one LDS round trip
@@ -360,6 +452,7 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, i
                                                               __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)n))] = c[u];
                             n += __popcll(mask);
                         }
+                        }
                     }
                     // P of the entries whose first chunk was in this group
                     const int tl = excl - tg;
@@ -384,13 +477,15 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, int64_t row_offset, i
         if (lane == 0) rowcnt[row] = n;
         // reset the marker for the next row (sparsework.cpp:120-128: memset when the row is
         // long, per-entry otherwise)
-        if (!LDSBM) __threadfence();
-        if (n >= bm_words) {
+        if (MARK == MARK_GLOBAL_BITMAP) __threadfence();
+        if (HASH) {
+            for (int w = lane; w < bm_words; w += WAVE) bm[w] = 0xffffffffu;
+        } else if (n >= bm_words) {
             for (int w = lane; w < bm_words; w += WAVE) bm[w] = 0;
         } else {
             for (int s2 = lane; s2 < n; s2 += WAVE) bm[out[s2] >> 5] = 0;
         }
-        if (!LDSBM) __threadfence();
+        if (MARK == MARK_GLOBAL_BITMAP) __threadfence();
     }
 }
 
@@ -772,15 +867,16 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
 // Row binning after the symbolic phase: rows of C with few nonzeros go to the hash kernels
 // below, the rest to the dense-tile kernel above.  lists[b] receives the rows of bin b (order
 // irrelevant), counts[b] their number.  bin 0: 1..small_max, bin 1: ..med_max, bin 2: larger.
+template <typename T>
 __global__ __launch_bounds__(256) void smm_bin_rows(int m, int small_max, int med_max,
-                                                    const int *__restrict__ rowcnt,
+                                                    const T *__restrict__ rowcnt,
                                                     int *__restrict__ lists, int *__restrict__ counts)
 {
     const int lane = lane_id();
     const int stride = gridDim.x * blockDim.x;
     for (int base = blockIdx.x * blockDim.x + threadIdx.x - lane; base < m; base += stride) {   // wave-uniform trip count
         const int row = base + lane;
-        const int n = row < m ? rowcnt[row] : 0;
+        const T n = row < m ? rowcnt[row] : 0;
         const int b = n <= 0 ? -1 : (n <= small_max ? 0 : (n <= med_max ? 1 : 2));
 #pragma unroll
         for (int bin = 0; bin < 3; ++bin) {                 // one atomic per wave and bin, not per row

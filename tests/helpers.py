@@ -8,6 +8,18 @@ def rand_csr(m, n, density, seed, dtype=np.float64):
     return sp.random(m, n, density=density, format="csr", random_state=np.random.default_rng(seed), dtype=dtype)
 
 
+def wide_csr(m, n, per_row, seed):
+    """~per_row distinct random columns per row for very wide matrices (scipy.sparse.random permutes all
+    m*n positions, which is hopeless at 1e6 columns)."""
+    rng = np.random.default_rng(seed)
+    cols = np.sort(rng.integers(0, n, size=(m, per_row)), axis=1)
+    keep = np.ones_like(cols, dtype=bool)
+    keep[:, 1:] = cols[:, 1:] != cols[:, :-1]
+    indptr = np.zeros(m + 1, np.int32)
+    indptr[1:] = np.cumsum(keep.sum(axis=1))
+    return sp.csr_matrix((rng.standard_normal(int(indptr[-1])), cols[keep].astype(np.int32), indptr), shape=(m, n))
+
+
 def arrays(m):
     return (np.ascontiguousarray(m.indptr, dtype=np.int32), np.ascontiguousarray(m.indices, dtype=np.int32),
             np.ascontiguousarray(m.data, dtype=np.float64))

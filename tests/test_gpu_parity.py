@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from helpers import arrays, assert_csr_equal, rand_csr, rel_err, shuffle_rows, signed
+from helpers import wide_csr, arrays, assert_csr_equal, rand_csr, rel_err, shuffle_rows, signed
 
 pytestmark = pytest.mark.gpu
 
@@ -67,6 +67,32 @@ def test_sparse_matches_oracle(ctx, oracle, m, k, n, da, db, symmetric, exact):
     want = oracle.sparse(arrays(A), arrays(B), n, symmetric=symmetric)
     got = _gpu_sparse(ctx, A, B, symmetric=symmetric, exact=exact)
     assert_csr_equal(got, want, values=_check_values(exact), rtol=RTOL)
+
+
+@pytest.mark.parametrize("n,ka,kb", [(200000, 10, 10), (200000, 16, 16), (200000, 45, 45), (70000, 12, 20), (1000000, 8, 12),
+                                     (300000, 3, 700)])
+@pytest.mark.parametrize("symmetric", [False, True])
+@pytest.mark.parametrize("exact", MODES)
+def test_sparse_wide_matrices_hash_marker(ctx, oracle, n, ka, kb, symmetric, exact):
+    """Very wide B: the symbolic phase marks columns in an LDS hash set for rows with <= 256 / <= 2048
+    products and in the bitmap for the rest; the cases sit inside the classes and on their boundaries."""
+    m = 600
+    A, B = wide_csr(m, 500, ka, 5), wide_csr(500, n, kb, 6)
+    if symmetric:                       # square result needed: pad A's rows to n
+        A = sp.vstack([A, sp.csr_matrix((n - m, 500))]).tocsr()
+    want = oracle.sparse(arrays(A), arrays(B), n, symmetric=symmetric)
+    got = _gpu_sparse(ctx, A, B, symmetric=symmetric, exact=exact)
+    assert_csr_equal(got, want, values=_check_values(exact), rtol=RTOL)
+
+
+@pytest.mark.parametrize("m", [32768, 32769, 100003])
+def test_sparse_many_rows(ctx, oracle, m):
+    """Row counts around and past the single-workgroup scan's limit (the row pointer comes from a
+    three-launch tiled scan above 32 768 rows), with empty rows in between."""
+    A, B = wide_csr(m, 300, 3, 7), wide_csr(300, 5000, 6, 8)
+    A = A.tolil(); A[5:900] = 0; A = A.tocsr(); A.eliminate_zeros()
+    want = oracle.sparse(arrays(A), arrays(B), 5000)
+    assert_csr_equal(_gpu_sparse(ctx, A, B, exact=True), want, values="bits")
 
 
 @pytest.mark.parametrize("lds_cols,waves", [(64, 1), (256, 4), (512, 8), (1000, 2), (5000, 1), (16384, 4), (20000, 8), (17000, 16), (300, 16)])
