@@ -809,8 +809,8 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
     } else {
         // Epilogue.  Step e of the row put its new columns of this tile into the contiguous slots
         // [runs[e][tc], runs[e][tc+1]).  The sub-runs are cut into 64-lane chunks; wave w takes the
-        // entries w, w+NW, ... of a round of 32*NW entries (long sub-runs belong to the first steps,
-        // so interleaving balances them), and for its <= 32 entries it finds the chunk list with one
+        // entries w, w+NW, ... of a round of 64*NW entries (long sub-runs belong to the first steps,
+        // so interleaving balances them), and for its <= 64 entries it finds the chunk list with one
         // scan, issues EPI_UNROLL chunk loads at a time and then stores.  The whole epilogue of a
         // unit costs a handful of memory round trips (an earlier version walked the entries 64 at a
         // time, one dependent round trip per batch and per long sub-run, and took 37 % of the kernel).
@@ -818,9 +818,9 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
         int *__restrict__ oi = A.c_idx + rs;
         double *__restrict__ ov = A.c_val + rs;
         const size_t per = (size_t)A.nct + 1;
-        for (int rb = a0; rb < a1; rb += NW * 32) {
+        for (int rb = a0; rb < a1; rb += NW * WAVE) {
             const int e = rb + wave + NW * lane;
-            const bool ev = lane < 32 && e < a1;
+            const bool ev = e < a1;
             const unsigned *rp = A.runs + (size_t)(ev ? e : a1 - 1) * per + tc;
             const unsigned r0 = rp[0];
             const unsigned r1 = ev ? rp[1] : r0;
