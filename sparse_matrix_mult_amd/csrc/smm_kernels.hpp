@@ -704,12 +704,12 @@ __device__ __forceinline__ void smm_accumulate_shared(const NumericArgs &A, doub
     const double *__restrict__ bv = A.b_val;
     const short *__restrict__ dummy_c = (const short *)A.dummy_idx;
 
-    // Wave w takes the A entries w, w+NW, ... of a round of 32*NW entries (the whole row when it
-    // has <= 512 entries): it alone loads their metadata (no NW-fold redundancy), cuts their
+    // Wave w takes the A entries w, w+NW, ... of a round of 64*NW entries (the whole row when it
+    // has <= 1024 entries): it alone loads their metadata (no NW-fold redundancy), cuts their
     // segments into 64-lane chunks with one scan, and then issues CH_UNROLL chunk loads at a time.
-    for (int rb = a0; rb < a1; rb += NW * 32) {
+    for (int rb = a0; rb < a1; rb += NW * WAVE) {
         const int e = rb + wave + NW * lane;
-        const bool ev = lane < 32 && e < a1;
+        const bool ev = e < a1;
         const int ec = ev ? e : a1 - 1;
         const int r = A.a_idx[ec];
         const double av = A.a_val[ec];
