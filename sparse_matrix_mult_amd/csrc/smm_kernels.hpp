@@ -687,6 +687,9 @@ __device__ __forceinline__ void smm_accumulate(const NumericArgs &A, double *__r
 // given up is the ORDER in which one accumulator receives its products, so values agree with
 // the reference to rounding (a few ulp; tests hold them to the north star's 1e-10) instead
 // of bit for bit.  SMM_EXACT selects smm_accumulate above instead.
+// (Measured dead end: the EXEC-masked, scalar-base chunk loads of smm_symbolic applied here made the
+// kernel slower, 29.5 -> 30.6 ms: it is bound by the gather, not by instruction issue, and the scalar
+// address arithmetic between the loads spreads their issue out.)
 #ifndef SMM_CH_UNROLL
 #define SMM_CH_UNROLL 16
 #endif
