@@ -627,13 +627,13 @@ static int scan_launch(smm_ctx *c, int64_t n, const T *in, int64_t *out)
     return SMM_OK;
 }
 
-template <bool SYM, bool SAFE, int MARK>
+template <bool SYM, bool SAFE, int MARK, int UNROLL = 16>
 static int launch_symbolic_t(smm_ctx *c, smm_plan *p, int words, unsigned *gbm, int grid, int wpb, const int *rowlist,
                              const int *d_nrows)
 {
     // LDS per wave: bitmap words + the guard word, or the hash slots
     const size_t lds = MARK == MARK_GLOBAL_BITMAP ? 0 : (size_t)(words + (MARK == MARK_LDS_HASH ? 0 : 1)) * wpb * sizeof(unsigned);
-    auto kern = smm_symbolic<SYM, SAFE, MARK>;
+    auto kern = smm_symbolic<SYM, SAFE, MARK, UNROLL>;
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     LAUNCH(c, MARK == MARK_LDS_HASH ? "smm_symbolic_hash" : "smm_symbolic", kern, grid, wpb * 64, lds, (int)p->m, rowlist,
@@ -730,23 +730,29 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     const int64_t nbm = hmax1 > 0 ? sbin[2] : m;
     const int *bm_rows = hmax1 > 0 ? d_slists + (size_t)2 * m : nullptr;
     const int *bm_count = hmax1 > 0 ? d_scounts + 2 : nullptr;
-    int wpb = 4;
+    int wpb = 4, waves_per_cu = 8;
     if (ldsbm) {
         int best = 0;
         for (int cand : {4, 2, 1}) {
             const int waves = (int)std::min<size_t>(32, ((size_t)160 * 1024 / (cand * bm_bytes)) * cand);
             if (waves > best) { best = waves; wpb = cand; }
         }
+        waves_per_cu = best;
     }
+    // few waves per CU (wide bitmaps): a round is one memory round trip whatever it carries -> 32 loads in flight
+    const bool deep = !safe && waves_per_cu <= 8;
     unsigned *gbm = nullptr;
     if (nbm > 0) {
         int sgrid = (int)std::min<int64_t>((nbm + wpb - 1) / wpb, (int64_t)c->n_cu * 8 * (4 / wpb));
         if (!ldsbm) PCHK(pool_get(c, (size_t)sgrid * wpb * (bm_words + 1), &gbm));
         const int mark = ldsbm ? MARK_LDS_BITMAP : MARK_GLOBAL_BITMAP;
-#define SYM_CASE(S, F, L) if (sym == S && safe == F && mark == L) PCHK((launch_symbolic_t<S, F, L>(c, p, bm_words, gbm, sgrid, wpb, bm_rows, bm_count)));
+#define SYM_CASE(S, F, L) if (sym == S && safe == F && mark == L && !deep) PCHK((launch_symbolic_t<S, F, L>(c, p, bm_words, gbm, sgrid, wpb, bm_rows, bm_count)));
         SYM_CASE(false, false, MARK_LDS_BITMAP) SYM_CASE(false, true, MARK_LDS_BITMAP) SYM_CASE(true, false, MARK_LDS_BITMAP)
         SYM_CASE(true, true, MARK_LDS_BITMAP) SYM_CASE(false, false, MARK_GLOBAL_BITMAP) SYM_CASE(false, true, MARK_GLOBAL_BITMAP)
         SYM_CASE(true, false, MARK_GLOBAL_BITMAP) SYM_CASE(true, true, MARK_GLOBAL_BITMAP)
+#define SYM_DEEP(S, L) if (sym == S && mark == L && deep) PCHK((launch_symbolic_t<S, false, L, 32>(c, p, bm_words, gbm, sgrid, wpb, bm_rows, bm_count)));
+        SYM_DEEP(false, MARK_LDS_BITMAP) SYM_DEEP(true, MARK_LDS_BITMAP) SYM_DEEP(false, MARK_GLOBAL_BITMAP) SYM_DEEP(true, MARK_GLOBAL_BITMAP)
+#undef SYM_DEEP
 #undef SYM_CASE
     }
     PCHK(scan_launch<int>(c, m, p->d_rowcnt, p->d_cptr));

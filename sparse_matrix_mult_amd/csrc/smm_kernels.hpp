@@ -73,13 +73,15 @@ __device__ __forceinline__ void wait_vm(int &v, int n) {
     switch (n) {
         SMM_W(0) SMM_W(1) SMM_W(2) SMM_W(3) SMM_W(4) SMM_W(5) SMM_W(6) SMM_W(7)
         SMM_W(8) SMM_W(9) SMM_W(10) SMM_W(11) SMM_W(12) SMM_W(13) SMM_W(14) SMM_W(15)
+        SMM_W(16) SMM_W(17) SMM_W(18) SMM_W(19) SMM_W(20) SMM_W(21) SMM_W(22) SMM_W(23)
+        SMM_W(24) SMM_W(25) SMM_W(26) SMM_W(27) SMM_W(28) SMM_W(29) SMM_W(30) SMM_W(31)
     }
 #undef SMM_W
 }
-__device__ __forceinline__ void wait_vm_all(int (&v)[16]) {
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
-                   "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+template <int N>
+__device__ __forceinline__ void wait_vm_all(int (&v)[N]) {
+#pragma unroll
+    for (int u = 0; u < N; ++u) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[u]));
 }
 
 __device__ __forceinline__ void lds_add(double *p, double x) {
@@ -290,9 +292,10 @@ __global__ __launch_bounds__(1024) void smm_scan_tiles(int n, const T *__restric
 // lanes keep the guard column and issue no request), then all test-and-sets, then consumes them
 // strictly in order.  The B-row pointers of the next 64 entries and the A indices of the 64 after
 // those are prefetched.
-constexpr int SYM_UNROLL = 16;        // chunk loads in flight per wave (8 and 32 measured slower); wait_vm_all is written for 16
+// SYM_UNROLL = chunk loads in flight per wave: 16 when many waves fit a CU (8 and 32 measured slower at
+// 50 000 columns, 24 waves); 32 when the bitmap leaves few waves per CU and a round is pure latency.
 enum { MARK_LDS_BITMAP = 0, MARK_GLOBAL_BITMAP = 1, MARK_LDS_HASH = 2 };
-template <bool SYM, bool SAFE, int MARK>
+template <bool SYM, bool SAFE, int MARK, int SYM_UNROLL>
 __global__ __launch_bounds__(256) void smm_symbolic(int m, const int *__restrict__ rowlist,
                                                     const int *__restrict__ nrows_p, int64_t row_offset, int bm_words,
                                                     const int *__restrict__ a_ptr,

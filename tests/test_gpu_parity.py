@@ -70,7 +70,7 @@ def test_sparse_matches_oracle(ctx, oracle, m, k, n, da, db, symmetric, exact):
 
 
 @pytest.mark.parametrize("n,ka,kb", [(200000, 10, 10), (200000, 16, 16), (200000, 45, 45), (70000, 12, 20), (1000000, 8, 12),
-                                     (300000, 3, 700)])
+                                     (300000, 3, 700), (1200000, 50, 50)])       # the last: bitmap in global memory
 @pytest.mark.parametrize("symmetric", [False, True])
 @pytest.mark.parametrize("exact", MODES)
 def test_sparse_wide_matrices_hash_marker(ctx, oracle, n, ka, kb, symmetric, exact):
