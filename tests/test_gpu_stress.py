@@ -58,6 +58,14 @@ CASES = [
     ("square_sym", lambda: (_skewed(350, 350, 9, 19, dense_rows=2), _skewed(350, 350, 9, 20, dense_rows=2))),
     ("square_sym_wide", lambda: (sp.random(600, 600, 0.02, format="csr", random_state=np.random.default_rng(21)),
                                  sp.random(600, 600, 0.02, format="csr", random_state=np.random.default_rng(22)))),
+    # rows of B of 20 000 entries: 313 chunks for one A entry, several 64-chunk descriptor groups per batch
+    ("long_b_rows", lambda: (sp.random(40, 60, 0.3, format="csr", random_state=np.random.default_rng(23)),
+                             _skewed(60, 20000, 50, 24, dense_rows=5))),
+    # 300 000 columns, Pareto row lengths: the rows of one product spread over both hash-marker classes and the bitmap
+    ("skew_wide_markers", lambda: (_skewed(400, 300, 6, 25, dense_rows=2), _skewed(300, 300000, 10, 26))),
+    # more than 64 A entries per row with empty rows of B in between (entries without chunks inside a batch)
+    ("gappy_b", lambda: (sp.random(50, 900, 0.4, format="csr", random_state=np.random.default_rng(27)),
+                         _skewed(900, 2000, 3, 28))),
 ]
 
 
