@@ -239,6 +239,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "smm_numeric", "kernel_ms": num_ms / max(num_n, 1),
                          "algorithmic_bytes": alg_bytes,
+                         # rate at which the kernel moves its measured HBM-side traffic (PMC bytes / live duration):
+                         # how close the gather itself runs to the 8 TB/s peak, as opposed to `frac`, which prices
+                         # only the compulsory bytes
+                         "traffic_rate_GBs": (traffic / num_avg_s / 1e9) if (traffic and num_avg_s > 0) else None,
                          "symbolic_kernel_ms": sym_ms / max(sym_n, 1)},
         }
         if not args.no_cpu and world == 1:           # the CPU leg runs at N = 1 only
