@@ -697,7 +697,7 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         PCHK(pool_get(c, (size_t)3 * m, &d_slists));
         hipError_t e = hipMemsetAsync(d_scounts, 0, 3 * sizeof(int), c->stream);
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "memset: %s", hipGetErrorString(e)); }
-        LAUNCH(c, "smm_bin_rows", smm_bin_rows<int64_t>, std::min<int64_t>((m + 255) / 256, 4096), 256, 0, (int)m, hmax0, hmax1,
+        LAUNCH(c, "smm_bin_rows", smm_bin_rows<int64_t>, std::min<int64_t>((m + 1023) / 1024, 2048), 1024, 0, (int)m, hmax0, hmax1,
                (const int64_t *)d_ub, d_slists, d_scounts);
     }
     int64_t total_ub = 0;
@@ -769,7 +769,7 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         PCHK(pool_get(c, (size_t)3 * m, &p->d_lists));
         int *d_counts = (int *)((char *)c->d_flags + 192);
         hipError_t e = hipMemsetAsync(d_counts, 0, 3 * sizeof(int), c->stream);
-        LAUNCH(c, "smm_bin_rows", smm_bin_rows<int>, std::min<int64_t>((m + 255) / 256, 4096), 256, 0, (int)m, c->hash_small,
+        LAUNCH(c, "smm_bin_rows", smm_bin_rows<int>, std::min<int64_t>((m + 1023) / 1024, 2048), 1024, 0, (int)m, c->hash_small,
                c->hash_medium, (const int *)p->d_rowcnt, p->d_lists, d_counts);
         if (e == hipSuccess) e = hipMemcpyAsync(p->n_bin, d_counts, 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

@@ -912,25 +912,33 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
 // below, the rest to the dense-tile kernel above.  lists[b] receives the rows of bin b (order
 // irrelevant), counts[b] their number.  bin 0: 1..small_max, bin 1: ..med_max, bin 2: larger.
 template <typename T>
-__global__ __launch_bounds__(256) void smm_bin_rows(int m, int small_max, int med_max,
-                                                    const T *__restrict__ rowcnt,
-                                                    int *__restrict__ lists, int *__restrict__ counts)
+__global__ __launch_bounds__(1024) void smm_bin_rows(int m, int small_max, int med_max,
+                                                     const T *__restrict__ rowcnt,
+                                                     int *__restrict__ lists, int *__restrict__ counts)
 {
-    const int lane = lane_id();
-    const int stride = gridDim.x * blockDim.x;
-    for (int base = blockIdx.x * blockDim.x + threadIdx.x - lane; base < m; base += stride) {   // wave-uniform trip count
-        const int row = base + lane;
+    __shared__ int wcnt[16][3], wbase[16][3];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    for (int base = blockIdx.x * 1024; base < m; base += gridDim.x * 1024) {        // workgroup-uniform trip count
+        const int row = base + threadIdx.x;
         const T n = row < m ? rowcnt[row] : 0;
         const int b = n <= 0 ? -1 : (n <= small_max ? 0 : (n <= med_max ? 1 : 2));
+        unsigned long long mine = 0ull;
 #pragma unroll
-        for (int bin = 0; bin < 3; ++bin) {                 // one atomic per wave and bin, not per row
+        for (int bin = 0; bin < 3; ++bin) {
             const unsigned long long mask = __ballot(b == bin);
-            if (mask == 0ull) continue;
-            int at = 0;
-            if (lane == 0) at = atomicAdd(&counts[bin], (int)__popcll(mask));
-            at = rl(at, 0);
-            if (b == bin) lists[(size_t)bin * m + at + mbcnt(mask)] = row;
+            if (b == bin) mine = mask;
+            if (lane == 0) wcnt[wave][bin] = (int)__popcll(mask);
         }
+        __syncthreads();
+        if (threadIdx.x < 3) {                              // one atomic per workgroup and bin, not per row
+            int total = 0;
+            for (int w = 0; w < 16; ++w) total += wcnt[w][threadIdx.x];
+            int at = total ? atomicAdd(&counts[threadIdx.x], total) : 0;
+            for (int w = 0; w < 16; ++w) { wbase[w][threadIdx.x] = at; at += wcnt[w][threadIdx.x]; }
+        }
+        __syncthreads();
+        if (b >= 0) lists[(size_t)b * m + wbase[wave][b] + mbcnt(mine)] = row;
+        __syncthreads();
     }
 }
 
