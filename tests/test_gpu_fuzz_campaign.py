@@ -66,3 +66,25 @@ def test_campaign(ctx, oracle, it):
             assert np.all(np.abs(gv - want[2]) <= 1e-12 * mag), f"max {np.max(np.abs(gv - want[2]) / np.maximum(mag, 1e-300)):.3e} of the magnitude sum"
     finally:
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("it", range(max(NCASES // 3, 1)))
+def test_campaign_triple(ctx, oracle, it):
+    """H Q H^T on random shapes: n across the 16-row blocks and 1024-row k-groups of stage 2, K across its
+    1024-column chunks; SMM_EXACT must reproduce the CPU loop bit for bit, upper triangle and full matrix."""
+    r = np.random.default_rng(SEED * 100000 + 50000 + it)
+    n, K = int(r.integers(1, 1400)), int(r.integers(1, 5000))
+    H = _rand_rows(r, n, K, 10 ** r.uniform(0, 1.5), int(r.integers(0, 3)))
+    S = sp.random(K, K, density=min(1.0, 10 ** r.uniform(0, 1.3) / K), format="csr", random_state=r)
+    Q = (S + S.T).tocsr()
+    Q.sort_indices()
+    if H is None or n * n * (H.nnz / max(n, 1)) > 6e8:
+        pytest.skip("case larger than the campaign's budget")
+    h, q = ctx.csr_from_scipy(H), ctx.csr_from_scipy(Q)
+    try:
+        for full in (0, 1):
+            want = oracle.triple(arrays(H), arrays(Q), K, full=full)
+            got = ctx.triple_host(h, q, full=bool(full), exact=True)
+            assert np.array_equal(got.view(np.int64), want.view(np.int64))
+    finally:
+        h.close(); q.close()
