@@ -8,14 +8,16 @@
 //
 // Design notes (DESIGN.md has the long form):
 //  * A row of C is accumulated in LDS as dense f64 tiles of <= lds_cols columns ("coarse
-//    tile").  Every wave of the workgroup owns a contiguous "fine tile" of it and walks the
+//    tile").  Default mode: all waves of the workgroup add into the tile concurrently (LDS atomics;
+//    values to rounding).  SMM_EXACT: every wave owns a contiguous "fine tile" of it and walks the
 //    row's A entries in stored order, so each accumulator receives its products in exactly the
-//    reference's order (one wave's LDS atomics execute in issue order): values are
-//    bit-identical to the CPU loop.
+//    reference's order (one wave's LDS atomics execute in issue order): values are bit-identical
+//    to the CPU loop.  Rows with few nonzeros take LDS hash kernels instead of tiles.
 //  * The first-touch column order of the reference is produced by smm_symbolic:
-//    one wave per row, a bitmap of B's columns in LDS, test-and-set + ballot/mbcnt ordered
-//    compaction.  The numeric kernel then emits indices/values in that order by gathering
-//    from the row it has just accumulated.
+//    one wave per row, a marker of B's columns in LDS (bitmap, or a hash set for rows with few
+//    products on wide matrices), test-and-set + ballot/mbcnt ordered compaction.  The numeric
+//    kernel then emits indices/values in that order straight from the tile it has just
+//    accumulated, as contiguous sub-runs (smm_runs).
 //  * No MFMA anywhere: this is an indexing / HBM path.
 #pragma once
 #include <hip/hip_runtime.h>
