@@ -6,3 +6,4 @@ f=$(find gpurun_out/prof_$TAG -name '*kernel_stats.csv' | head -1)
 (head -1 $f; grep smm:: $f) > gpurun_out/${TAG}_sparse_1e6_kernel_stats.csv
 grep '^{' gpurun_out/prof_$TAG.log > gpurun_out/${TAG}_sparse_1e6_bench.json
 cut -c1-150 gpurun_out/${TAG}_sparse_1e6_kernel_stats.csv; cut -c1-300 gpurun_out/${TAG}_sparse_1e6_bench.json
+rm -rf gpurun_out/prof_$TAG
