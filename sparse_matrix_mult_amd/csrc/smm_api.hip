@@ -629,7 +629,7 @@ static int scan_launch(smm_ctx *c, int64_t n, const T *in, int64_t *out)
 
 template <bool SYM, bool SAFE, int MARK, int UNROLL = 16>
 static int launch_symbolic_t(smm_ctx *c, smm_plan *p, int words, unsigned *gbm, int grid, int wpb, const int *rowlist,
-                             const int *d_nrows)
+                             const int *d_nrows, int *d_row_counter)
 {
     // LDS per wave: bitmap words + the guard word, or the hash slots
     const size_t lds = MARK == MARK_GLOBAL_BITMAP ? 0 : (size_t)(words + (MARK == MARK_LDS_HASH ? 0 : 1)) * wpb * sizeof(unsigned);
@@ -638,7 +638,7 @@ static int launch_symbolic_t(smm_ctx *c, smm_plan *p, int words, unsigned *gbm, 
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     LAUNCH(c, MARK == MARK_LDS_HASH ? "smm_symbolic_hash" : "smm_symbolic", kern, grid, wpb * 64, lds, (int)p->m, rowlist,
            d_nrows, p->row_offset, words, p->a->ptr, p->a->idx, p->b->ptr, p->b->idx, p->d_ub_off, p->d_tmp, p->d_P,
-           p->d_rowcnt, gbm);
+           p->d_rowcnt, gbm, d_row_counter);
     LAUNCH_CHECK();
     return SMM_OK;
 }
@@ -717,13 +717,19 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "memset: %s", hipGetErrorString(e)); }
     }
 
+    // the kernels hand rows out through these counters (one per launch)
+    int *d_rowctr = (int *)((char *)c->d_flags + 208);
+    {
+        hipError_t e = hipMemsetAsync(d_rowctr, 0, 3 * sizeof(int), c->stream);
+        if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "memset: %s", hipGetErrorString(e)); }
+    }
     // hash classes: one wave per row, four rows per workgroup
     for (int cls = 0; cls < 2; ++cls) {
         if (hmax1 == 0 || sbin[cls] == 0) continue;
         const int hs = cls == 0 ? HS0 : HS1;
         const int hgrid = (int)std::min<int64_t>((sbin[cls] + 3) / 4, (int64_t)c->n_cu * 16);
-        if (sym) PCHK((launch_symbolic_t<true, false, MARK_LDS_HASH>(c, p, hs, nullptr, hgrid, 4, d_slists + (size_t)cls * m, d_scounts + cls)));
-        else     PCHK((launch_symbolic_t<false, false, MARK_LDS_HASH>(c, p, hs, nullptr, hgrid, 4, d_slists + (size_t)cls * m, d_scounts + cls)));
+        if (sym) PCHK((launch_symbolic_t<true, false, MARK_LDS_HASH>(c, p, hs, nullptr, hgrid, 4, d_slists + (size_t)cls * m, d_scounts + cls, d_rowctr + cls)));
+        else     PCHK((launch_symbolic_t<false, false, MARK_LDS_HASH>(c, p, hs, nullptr, hgrid, 4, d_slists + (size_t)cls * m, d_scounts + cls, d_rowctr + cls)));
     }
     // bitmap kernels for the rest: one wave per row; waves per workgroup are chosen so that as many
     // waves as possible fit a CU's 160 KB
@@ -746,11 +752,11 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         int sgrid = (int)std::min<int64_t>((nbm + wpb - 1) / wpb, (int64_t)c->n_cu * 8 * (4 / wpb));
         if (!ldsbm) PCHK(pool_get(c, (size_t)sgrid * wpb * (bm_words + 1), &gbm));
         const int mark = ldsbm ? MARK_LDS_BITMAP : MARK_GLOBAL_BITMAP;
-#define SYM_CASE(S, F, L) if (sym == S && safe == F && mark == L && !deep) PCHK((launch_symbolic_t<S, F, L>(c, p, bm_words, gbm, sgrid, wpb, bm_rows, bm_count)));
+#define SYM_CASE(S, F, L) if (sym == S && safe == F && mark == L && !deep) PCHK((launch_symbolic_t<S, F, L>(c, p, bm_words, gbm, sgrid, wpb, bm_rows, bm_count, d_rowctr + 2)));
         SYM_CASE(false, false, MARK_LDS_BITMAP) SYM_CASE(false, true, MARK_LDS_BITMAP) SYM_CASE(true, false, MARK_LDS_BITMAP)
         SYM_CASE(true, true, MARK_LDS_BITMAP) SYM_CASE(false, false, MARK_GLOBAL_BITMAP) SYM_CASE(false, true, MARK_GLOBAL_BITMAP)
         SYM_CASE(true, false, MARK_GLOBAL_BITMAP) SYM_CASE(true, true, MARK_GLOBAL_BITMAP)
-#define SYM_DEEP(S, L) if (sym == S && mark == L && deep) PCHK((launch_symbolic_t<S, false, L, 32>(c, p, bm_words, gbm, sgrid, wpb, bm_rows, bm_count)));
+#define SYM_DEEP(S, L) if (sym == S && mark == L && deep) PCHK((launch_symbolic_t<S, false, L, 32>(c, p, bm_words, gbm, sgrid, wpb, bm_rows, bm_count, d_rowctr + 2)));
         SYM_DEEP(false, MARK_LDS_BITMAP) SYM_DEEP(true, MARK_LDS_BITMAP) SYM_DEEP(false, MARK_GLOBAL_BITMAP) SYM_DEEP(true, MARK_GLOBAL_BITMAP)
 #undef SYM_DEEP
 #undef SYM_CASE
