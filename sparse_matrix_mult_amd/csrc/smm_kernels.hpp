@@ -335,20 +335,19 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, const int *__restrict
     if (!HASH && lane == 0) bm[bm_words] = 0xffffffffu;
     if (MARK == MARK_GLOBAL_BITMAP) __threadfence();
 
-    // Rows are handed out by a global counter, in order: a static split leaves the waves of the last,
-    // partial round of workgroups running alone (2048 workgroups on 1536 resident ones cost 25 %), and
-    // rows differ in work anyway.  Every wave leaves when the counter passes the last row.
-    // (Rows of the hash classes are tiny: they go out 32 at a time, or 1e6 atomics on one word cost 10 ms.)
-    constexpr int GRAB = HASH ? 32 : 1;
-    int ri = 0, ri_end = 0;
-    for (;;) {
-        if (ri == ri_end) {
-            if (lane == 0) ri = atomicAdd(row_counter, GRAB);
+    // Bitmap kernels: rows are handed out by a global counter, in order: a static split leaves the waves
+    // of the last, partial round of workgroups running alone (2048 workgroups on 1536 resident ones
+    // cost 25 %), and rows differ in work anyway.  Every wave leaves when the counter passes the
+    // last row.  Hash classes: the rows are tiny and there are up to 1e6 of them -- that many atomics
+    // on one word cost more than they balance (measured), so those keep the interleaved static split.
+    for (int rs = blockIdx.x * wpb + wave;; rs += gridDim.x * wpb) {
+        int ri = rs;
+        if (!HASH) {
+            if (lane == 0) ri = atomicAdd(row_counter, 1);
             ri = rl(ri, 0);
-            ri_end = ri + GRAB < nrows ? ri + GRAB : nrows;
-            if (ri >= nrows) break;
         }
-        const int row = rowlist ? rowlist[ri++] : ri++;
+        if (ri >= nrows) break;
+        const int row = rowlist ? rowlist[ri] : ri;
         const int a0 = a_ptr[row], a1 = a_ptr[row + 1];
         int thresh = 0;
         if (SYM) { const int64_t gi = row + row_offset; thresh = gi > 0x7fffffff ? 0x7fffffff : (int)gi; }
