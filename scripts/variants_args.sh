@@ -4,7 +4,7 @@ ARGS="$1"; shift
 for v in "$@"; do
   export SMM_LIB_PATH=$GRAFT_REPO_ROOT/sparse_matrix_mult_amd/lib/$v
   [ "$v" = "default" ] && unset SMM_LIB_PATH
-  timeout -k 10 200 python bench.py --steps 3 --warmup 1 --no-cpu $ARGS > gpurun_out/va_$v.log 2>&1 || { echo FAIL $v; tail -3 gpurun_out/va_$v.log; }
+  timeout -k 10 200 python bench.py --steps ${STEPS:-3} --warmup 1 --no-cpu $ARGS > gpurun_out/va_$v.log 2>&1 || { echo FAIL $v; tail -3 gpurun_out/va_$v.log; }
   python3 - "$v" <<'PY'
 import json, sys
 for l in open(f"gpurun_out/va_{sys.argv[1]}.log"):
