@@ -511,8 +511,8 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, const int *__restrict
 // order (B's rows are sorted), so the part that falls into coarse tile t is the contiguous
 // slot range [runs[e][t], runs[e][t+1]).  One wave per row, one lane per A entry, nct-1
 // lower_bounds each.  The list segments of 64 consecutive entries are one contiguous piece of the
-// row's list: the wave copies it into LDS with coalesced loads, RUNS_WIN entries at a time, and the
-// lanes search there (a first version searched in global memory: ~70 dependent probes per lane into
+// row's list: the wave copies the list into LDS with coalesced loads, RUNS_WIN entries at a time (the
+// next window is already on its way while one is searched), and the lanes search there (a first version searched in global memory: ~70 dependent probes per lane into
 // lines nobody else used, 19 ms at 200 000 columns / 10 tiles; this one streams the list once).
 constexpr int RUNS_WIN = 2048;
 __global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc, const int *__restrict__ rowlist,
@@ -524,6 +524,7 @@ __global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc, const in
                                                 unsigned *__restrict__ runs)
 {
     __shared__ int win_all[4][RUNS_WIN];
+    constexpr int NV = RUNS_WIN / WAVE;            // window elements per lane
     const int lane = lane_id();
     const int wpb = blockDim.x / WAVE;              // 4
     int *win = win_all[threadIdx.x >> 6];
@@ -532,6 +533,18 @@ __global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc, const in
         const int a0 = a_ptr[row], a1 = a_ptr[row + 1];
         const int *__restrict__ list = tmp_idx + ub_off[row];
         const unsigned total = (unsigned)rowcnt[row];
+        // The row's list is cut into fixed windows of RUNS_WIN entries.  Window k sits in LDS while
+        // window k+1 travels in registers (its loads are issued before the searches in window k).
+        int v[NV];
+        auto fetch = [&](unsigned wb) {             // window [wb, wb + RUNS_WIN) of the list -> registers
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const unsigned i = wb + u * WAVE + lane;
+                v[u] = list[i < total ? i : (total ? total - 1 : 0)];
+            }
+        };
+        unsigned cur = 0xffffffffu;                 // start of the window that is in LDS
+        if (total) fetch(0);
         for (int eb = a0; eb < a1; eb += WAVE) {
             const int e = eb + lane;
             const bool valid = e < a1;
@@ -546,22 +559,16 @@ __global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc, const in
                 tcur = nct;
             }
             const unsigned reg_lo = rl(p0, 0), reg_hi = rl(p1, WAVE - 1);
-            for (unsigned wb = reg_lo; wb < reg_hi; wb += RUNS_WIN) {
-                const unsigned we = wb + RUNS_WIN < reg_hi ? wb + RUNS_WIN : reg_hi;
-                for (unsigned i0 = wb + lane; i0 < we + lane; i0 += 16 * WAVE) {     // 16 loads in flight
-                    int v[16];
+            for (unsigned wb = reg_lo - reg_lo % RUNS_WIN; wb < reg_hi; wb += RUNS_WIN) {
+                const unsigned we = wb + RUNS_WIN < total ? wb + RUNS_WIN : total;
+                if (wb != cur) {                    // bring the window in (it is in v), request the next one
+                    wave_sync();
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const unsigned i = i0 + u * WAVE;
-                        v[u] = list[i < we ? i : we - 1];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const unsigned i = i0 + u * WAVE;
-                        if (i < we) win[i - wb] = v[u];
-                    }
+                    for (int u = 0; u < NV; ++u) win[u * WAVE + lane] = v[u];
+                    cur = wb;
+                    if (we < total) fetch(we);
+                    wave_sync();
                 }
-                wave_sync();
                 unsigned lo = p0 > wb ? p0 : wb;
                 const unsigned hiw = p1 < we ? p1 : we;
                 if (lo < hiw) {
@@ -577,7 +584,6 @@ __global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc, const in
                         else break;                                              // it goes on in the next window
                     }
                 }
-                wave_sync();
             }
         }
     }
