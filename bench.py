@@ -1,29 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the CSR x CSR -> CSR hot path on MI355X.
+"""bench.py -- headline benchmark of the CSR x CSR hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows 50000] [--cols 50000] [--density 0.01]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c1|c2|c3|c4] [--gather] [--exact]
 
-Workload (BASELINE.json configs[1]): A (rows x cols) times B (cols x cols), both uniform
-random CSR of the given density with uniform[0,1) float64 values -- the distribution of
-scipy.sparse.random, generated on the device (inputs are resident in HBM before the timed
-region; nothing from the host is in it).  One step = one whole product: symbolic phase
+Default workload (BASELINE.json configs[1], `--config c1`): A (50 000 x 50 000) times B (50 000 x
+50 000), both uniform random CSR of density 0.01 with uniform[0,1) float64 values -- the
+distribution of scipy.sparse.random, generated on the device (inputs are resident in HBM before
+the timed region; nothing from the host is in it).  One step = one whole product: symbolic phase
 (row counts + first-touch column order), scan, numeric phase, result left in HBM.
+The other BASELINE configs can be timed with the same harness (they are parity-test cases, not
+the driver's bench line): c2 = the same product -> dense, c3 = H Q H^T with H 20 000 x 80 000
+d=0.02 and Q 80 000^2 symmetric d=0.005, c4 = one rank's share of 200 000^2 d=0.005 per GPU.
 
-Multi-GPU (weak scaling): rank r owns the contiguous row block [r*rows, (r+1)*rows) of a
-global (N*rows x cols) A; B is replicated.  The exchange step is the all-gather of the
-shards' row counts that turns local row pointers into the global CSR row pointer
+Multi-GPU (weak scaling): rank r owns the contiguous row block [r*rows, (r+1)*rows) of a global
+(N*rows x cols) A; B is replicated.  The exchange step is the all-gather of the shards' row
+counts that turns local row pointers into the global CSR row pointer
 (sparse_matrix_mult_amd/distributed.py); indices/values stay sharded (a full all-gatherv of
-N x 30 GB does not fit one GPU at this size -- DESIGN.md "Multi-GPU").
+N x 30 GB does not fit one GPU at this size -- DESIGN.md "Multi-GPU").  `--gather` runs the full
+variable-length all-gather of indices/values inside the step at a size where the whole C fits
+every GPU (SURVEY 8e option ii: 200 000^2, d = 0.001, rows split over the ranks: strong scaling).
+`python bench.py --gpus N` without a launcher starts its N ranks itself (torch.distributed.run
+as a child process, before this process touches the GPU).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- algorithmic bytes of one product / average duration of the dominant kernel
-                  (smm_numeric), measured with HIP events on the launch stream
+  roofline     -- algorithmic bytes of one product / duration of the numeric phase's kernels,
+                  measured with HIP events on the launch stream
   cpu_baseline -- the CPU oracle (oracle/, a port of the reference's algorithm) timed on a
                   bounded row sample of the same operands on this box's host cores
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,30 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
-
-
-def gen_csr_device(torch, rows, cols, density, seed, device):
-    """Uniform random CSR on the device: every cell is kept with probability `density`
-    (row lengths are binomial, as scipy.sparse.random's are to within sampling noise),
-    indices sorted inside rows, values uniform[0,1) float64."""
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    chunk = max(1, min(rows, (64 << 20) // max(cols, 1)))
-    idx_parts, cnt_parts = [], []
-    for r0 in range(0, rows, chunk):
-        r1 = min(rows, r0 + chunk)
-        mask = torch.rand((r1 - r0, cols), generator=g, device=device) < density
-        nz = mask.nonzero(as_tuple=False)                 # row-major -> sorted inside rows
-        idx_parts.append(nz[:, 1].to(torch.int32))
-        cnt_parts.append(mask.sum(dim=1))
-        del mask, nz
-    indices = torch.cat(idx_parts)
-    counts = torch.cat(cnt_parts)
-    indptr = torch.zeros(rows + 1, dtype=torch.int64, device=device)
-    indptr[1:] = torch.cumsum(counts, 0)
-    assert int(indptr[-1]) < 2 ** 31
-    data = torch.rand(indices.numel(), generator=g, device=device, dtype=torch.float64)
-    return indptr.to(torch.int32), indices, data
+NUMERIC_KERNELS = ("smm_numeric", "smm_dense_slab", "smm_emit")      # kernels of the numeric phase (whichever ran)
 
 
 def cpu_baseline(torch, a, b, cols, gpu_result=None, target_s=12.0):
@@ -106,14 +92,35 @@ def cpu_baseline(torch, a, b, cols, gpu_result=None, target_s=12.0):
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher: start the N ranks as a fresh child process tree
+    (torch.distributed.run) BEFORE this process makes any GPU call, pass its output through."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--rows", type=int, default=50000)
-    ap.add_argument("--cols", type=int, default=50000)
-    ap.add_argument("--density", type=float, default=0.01)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c1", choices=["c1", "c2", "c3", "c4"],
+                    help="BASELINE config: c1 50k^2 -> sparse (default, the bench line), c2 -> dense, c3 triple product, "
+                         "c4 one rank's share of 200k^2 per GPU")
+    ap.add_argument("--rows", type=int, default=0)
+    ap.add_argument("--cols", type=int, default=0)
+    ap.add_argument("--density", type=float, default=0.0)
+    ap.add_argument("--scale", type=float, default=1.0, help="c3 only: scale both dimensions of H")
+    ap.add_argument("--gather", action="store_true",
+                    help="sparse configs: all-gatherv of indices/values inside the step, rows split over the ranks "
+                         "(default size 200000^2 d=0.001, SURVEY 8e option ii)")
     ap.add_argument("--exact", action="store_true", help="SMM_EXACT: reference-order accumulation (bit-exact values)")
     ap.add_argument("--lds-cols", type=int, default=0)
     ap.add_argument("--waves", type=int, default=0)
@@ -121,14 +128,14 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-        args.gpus = world
+    args.gpus = world
     # SMM_BENCH_REHEARSAL=1: every rank on GPU 0 with gloo collectives -- a way to rehearse the
     # N > 1 code path on a one-GPU box (RCCL refuses two ranks on one device).  Never a result.
     rehearsal = os.environ.get("SMM_BENCH_REHEARSAL", "0") == "1"
@@ -147,32 +154,64 @@ def main():
 
     from sparse_matrix_mult_amd.engine import Context
     from sparse_matrix_mult_amd import distributed as smm_dist
+    from sparse_matrix_mult_amd.synthetic import gen_csr_device, gen_symmetric_csr_device
 
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = Context(local, stream)
+    # The library launches on torch's current stream (0 = the null stream -> SMM_STREAM_DEFAULT): the
+    # generator's kernels, the product's kernels and the events below are all ordered on it.
+    tstream = torch.cuda.current_stream()
+    ctx = Context(local, tstream.cuda_stream)
     if args.lds_cols or args.waves:
         (ctx.tune if args.exact else ctx.tune_shared)(args.lds_cols, args.waves)
-
     if args.hash:
         ctx.tune_hash(*[int(x) for x in args.hash.split(",")])
 
-    m, n, d = args.rows, args.cols, args.density
-    a_t = gen_csr_device(torch, m, n, d, 1 + 1000 * rank, device)      # rank's row block of A
-    b_t = gen_csr_device(torch, n, n, d, 2, device)                   # B, replicated
-    A = ctx.csr_from_torch(m, n, *a_t)
-    B = ctx.csr_from_torch(n, n, *b_t)
+    cfg = args.config
+    if cfg == "c3":
+        n, k = int(20000 * args.scale), int(80000 * args.scale)
+        m, d = n, 0.02
+        A = ctx.csr_from_torch(n, k, *gen_csr_device(torch, n, k, 0.02, 3, device))                 # H
+        B = ctx.csr_from_torch(k, k, *gen_symmetric_csr_device(torch, k, 0.005, 4, device))         # Q
+        # rows of the result are split over the ranks by sum(n - i) (strong scaling of one product)
+        r0, r1 = smm_dist.triple_row_shards(n, world)[rank] if rank < n else (n, n)
+        out_buf = torch.empty((r1 - r0, n), dtype=torch.float64, device=device)
+        a_t = b_t = None
+    else:
+        if args.gather and not (args.rows or args.cols or args.density):
+            n, d = 200000, 0.001
+            m = n // world
+        elif cfg == "c4":
+            n, d = args.cols or 200000, args.density or 0.005
+            m = args.rows or n // 8                                 # one rank's share of the 8-way split
+        else:
+            n, d = args.cols or 50000, args.density or 0.01
+            m = args.rows or 50000
+        a_t = gen_csr_device(torch, m, n, d, 1 + 1000 * rank, device)      # rank's row block of A
+        b_t = gen_csr_device(torch, n, n, d, 2, device)                    # B, replicated
+        A = ctx.csr_from_torch(m, n, *a_t)
+        B = ctx.csr_from_torch(n, n, *b_t)
+        out_buf = torch.empty((m, n), dtype=torch.float64, device=device) if cfg == "c2" else None
     nnz_a, nnz_b = A.nnz, B.nnz
 
     def step():
+        if cfg == "c2":
+            ctx.dense_into(A, B, out_buf.data_ptr(), row_offset=rank * m, exact=args.exact)
+            return (out_buf,)
+        if cfg == "c3":
+            ctx.triple_into(A, B, out_buf.data_ptr(), row_begin=r0, row_end=r1, exact=args.exact)
+            return (out_buf,)
         plan = ctx.spgemm_plan(A, B, row_offset=rank * m, exact=args.exact)
         indptr = torch.empty(m + 1, dtype=torch.int64, device=device)
         indices = torch.empty(plan.nnz, dtype=torch.int32, device=device)
         data = torch.empty(plan.nnz, dtype=torch.float64, device=device)
         plan.numeric_into(indptr.data_ptr(), indices.data_ptr(), data.data_ptr())
         plan.close()
+        local_nnz = indices.numel()
         if world > 1:
-            indptr = smm_dist.global_indptr(indptr, dist, equal_rows=True)   # the exchange step
-        return indptr, indices, data
+            if args.gather:                                          # the whole C on every rank
+                indptr, indices, data = smm_dist.allgather_csr(indptr, indices, data, dist)
+            else:                                                    # the exchange step: global row pointer
+                indptr = smm_dist.global_indptr(indptr, dist, equal_rows=True)
+        return indptr, indices, data, local_nnz
 
     def fence():
         torch.cuda.synchronize()
@@ -185,68 +224,108 @@ def main():
         del out
     ctx.timing(True)
     ctx.timing_reset()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    units = 0
     fence()
     t0 = time.perf_counter()
+    marks[0].record(tstream)
     for it in range(args.steps):
         out = step()
-        nnz_c = int(out[1].numel())
-        if it + 1 < args.steps or args.no_cpu or world > 1:
+        units = out[3] if len(out) == 4 else out[0].numel()
+        marks[it + 1].record(tstream)
+        if it + 1 < args.steps or args.no_cpu or world > 1 or cfg != "c1":
             del out                               # rank 0 keeps the last result for the parity check
     fence()
     elapsed = time.perf_counter() - t0
-    num_ms, num_n = ctx.kernel_time("smm_numeric")
-    sym_ms, sym_n = ctx.kernel_time("smm_symbolic")
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    ktimes = {k: ctx.kernel_time(k) for k in NUMERIC_KERNELS + ("smm_numeric_dense", "smm_symbolic", "smm_runs", "smm_triple_stage2")}
     ctx.timing(False)
 
-    t = torch.tensor([elapsed, float(nnz_c)], dtype=torch.float64, device="cpu" if rehearsal else device)
+    t = torch.tensor([elapsed, float(units)], dtype=torch.float64, device="cpu" if rehearsal else device)
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed, total_nnz = float(tmax[0]), float(t[1])
+        elapsed, total_units = float(tmax[0]), float(t[1])
     else:
-        total_nnz = float(nnz_c)
+        total_units = float(units)
 
     if rank == 0:
-        # HBM traffic of the dominant kernel, from the committed PMC passes of this same workload
-        # (rocprofv3 cannot run inside the bench; profiles/traffic_r1.json says how it was taken)
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r1.json")))
-            if (m, n, d) == (50000, 50000, 0.01) and not args.exact and not (args.lds_cols or args.waves):
-                traffic = tj["traffic_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            pass
-        # compulsory one-touch bytes of one product
-        alg_bytes = (4 * (m + 1) + 12 * nnz_a) + (4 * (n + 1) + 12 * nnz_b) + (8 * (m + 1) + 12 * nnz_c)
-        num_avg_s = (num_ms / max(num_n, 1)) * 1e-3
-        achieved = alg_bytes / num_avg_s / 1e9 if num_avg_s > 0 else 0.0
+        per_launch = lambda name: ktimes[name][0] / max(args.steps, 1)          # ms per step spent in that kernel
         line = {
-            "metric": "output nnz/sec, CSR x CSR -> CSR SpGEMM (first-touch order, float64)",
-            "value": total_nnz * args.steps / elapsed,
-            "unit": "nnz/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step_best": step_ms[0], "ms_per_step_median": step_ms[len(step_ms) // 2],
+            "higher_is_better": True, "scaling": "strong" if (args.gather or cfg == "c3") else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{m}x{n} x {n}x{n} uniform random CSR d={d} -> CSR, per GPU "
-                                   f"(BASELINE configs[1])",
-                       "nnz_a": nnz_a, "nnz_b": nnz_b, "nnz_c_per_gpu": nnz_c,
-                       "mode": "SMM_EXACT (values bit-identical to the CPU loop)" if args.exact
-                               else "default (indices bit-exact, values to rounding)",
-                       "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "smm_numeric", "kernel_ms": num_ms / max(num_n, 1),
-                         "algorithmic_bytes": alg_bytes,
-                         # rate at which the kernel moves its measured HBM-side traffic (PMC bytes / live duration):
-                         # how close the gather itself runs to the 8 TB/s peak, as opposed to `frac`, which prices
-                         # only the compulsory bytes
-                         "traffic_rate_GBs": (traffic / num_avg_s / 1e9) if (traffic and num_avg_s > 0) else None,
-                         "symbolic_kernel_ms": sym_ms / max(sym_n, 1)},
         }
-        if not args.no_cpu and world == 1:           # the CPU leg runs at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(torch, a_t, b_t, n, (out[0], out[1], out[2]))
+        mode = "SMM_EXACT (values bit-identical to the CPU loop)" if args.exact else "default (indices bit-exact, values to rounding)"
+        par = f"row-sharded x{world}" if world > 1 else "single GPU"
+        if cfg in ("c1", "c4"):
+            nnz_c = units
+            # compulsory one-touch bytes of one product
+            alg_bytes = (4 * (m + 1) + 12 * nnz_a) + (4 * (n + 1) + 12 * nnz_b) + (8 * (m + 1) + 12 * nnz_c)
+            num_ms = sum(per_launch(k) for k in NUMERIC_KERNELS)
+            # HBM traffic of the numeric phase, from the committed PMC passes of this same workload
+            # (rocprofv3 cannot run inside the bench; profiles/ says how it was taken)
+            traffic, traffic_src = None, None
+            ran = sorted(k for k in NUMERIC_KERNELS if per_launch(k) > 0)
+            for name in ("traffic_r2.json", "traffic_r1.json"):
+                try:
+                    tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+                    if (m, n, d) == (50000, 50000, 0.01) and not args.exact and not (args.lds_cols or args.waves) \
+                            and sorted(tj.get("kernels", ["smm_numeric"])) == ran:
+                        traffic = tj["traffic_bytes_per_launch"]
+                        traffic_src = f"profiles/{name} (static: PMC passes of this workload and these kernels, not measured in this run)"
+                        break
+                except (OSError, ValueError, KeyError):
+                    pass
+            achieved = alg_bytes / (num_ms * 1e-3) / 1e9 if num_ms > 0 else 0.0
+            line.update({
+                "metric": "output nnz/sec, CSR x CSR -> CSR SpGEMM (first-touch order, float64)",
+                "value": total_units * args.steps / elapsed, "unit": "nnz/s",
+                "config": {"workload": f"{m}x{n} x {n}x{n} uniform random CSR d={d} -> CSR, per GPU "
+                                       f"(BASELINE configs[{1 if cfg == 'c1' else 4}]{', all-gatherv inside the step' if args.gather else ''})",
+                           "nnz_a": nnz_a, "nnz_b": nnz_b, "nnz_c_per_gpu": nnz_c, "mode": mode, "parallelism": par},
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                             "kernel": "numeric phase: " + " + ".join(k for k in NUMERIC_KERNELS if per_launch(k) > 0),
+                             "kernel_ms": num_ms,
+                             "kernels_ms": {k: per_launch(k) for k in ktimes if per_launch(k) > 0},
+                             "algorithmic_bytes": alg_bytes,
+                             # rate at which the phase moves its measured HBM-side traffic (PMC bytes / live duration)
+                             "traffic_rate_GBs": (traffic / (num_ms * 1e-3) / 1e9) if (traffic and num_ms > 0) else None,
+                             "whole_step_frac": alg_bytes / (step_ms[len(step_ms) // 2] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "symbolic_kernel_ms": per_launch("smm_symbolic")},
+            })
+            if not args.no_cpu and world == 1 and cfg == "c1":           # the CPU leg runs at N = 1 only
+                line["cpu_baseline"] = cpu_baseline(torch, a_t, b_t, n, (out[0], out[1], out[2]))
+        elif cfg == "c2":
+            alg_bytes = (4 * (m + 1) + 12 * nnz_a) + (4 * (n + 1) + 12 * nnz_b) + 8 * m * n
+            num_ms = per_launch("smm_numeric_dense") + per_launch("smm_dense_slab")
+            achieved = alg_bytes / (num_ms * 1e-3) / 1e9 if num_ms > 0 else 0.0
+            line.update({
+                "metric": "output elements/sec, CSR x CSR -> dense (float64)",
+                "value": total_units * args.steps / elapsed, "unit": "elements/s",
+                "config": {"workload": f"{m}x{n} x {n}x{n} uniform random CSR d={d} -> dense, per GPU (BASELINE configs[2])",
+                           "nnz_a": nnz_a, "nnz_b": nnz_b, "mode": mode, "parallelism": par},
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": num_ms,
+                             "kernels_ms": {k: per_launch(k) for k in ktimes if per_launch(k) > 0},
+                             "algorithmic_bytes": alg_bytes},
+            })
+        else:
+            nn, kk = A.rows, A.cols
+            fma = nnz_a * (nnz_b / kk) + nn * (nn + 1) / 2 * (nnz_a / nn)       # stage 1 products + stage 2 gather-FMAs
+            line.update({
+                "metric": "multiply-adds/sec, H Q H^T upper triangle (float64)",
+                "value": fma * args.steps / elapsed, "unit": "FMA/s",
+                "config": {"workload": f"H {nn}x{kk} d=0.02, Q {kk}x{kk} symmetric d~0.005 -> dense upper triangle "
+                                       f"(BASELINE configs[3])", "nnz_h": nnz_a, "nnz_q": nnz_b, "mode": mode, "parallelism": par},
+                "roofline": {"bound": "vector-fp64 / LDS gather (no MFMA: an indexing path)", "achieved": 2 * fma * args.steps / elapsed / 1e12,
+                             "peak": 78.6, "unit": "TFLOP/s", "frac": 2 * fma * args.steps / elapsed / 1e12 / 78.6, "traffic": None,
+                             "kernels_ms": {k: per_launch(k) for k in ktimes if per_launch(k) > 0}},
+            })
         print(json.dumps(line), flush=True)
 
     A.close(); B.close(); ctx.close()

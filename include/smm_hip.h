@@ -52,14 +52,19 @@ typedef struct smm_csr  smm_csr;   /* a CSR operand resident in HBM (+ cached ti
 typedef struct smm_plan smm_plan;  /* result of the symbolic phase of one product         */
 
 /* ------------------------------------------------------------------ context
- * A context owns one device, one stream and a workspace pool.  It is NOT thread-safe: use one
- * context per host thread (the legacy symbols below share one context and serialise on it).
+ * A context owns one device, one stream and a workspace pool.  Every entry point takes the
+ * context's lock, so host threads may share one context (their calls serialise; the reference's
+ * library has no global state and is called with the GIL released, matrix_ops.py:136).
  * Handles (smm_csr, smm_plan) belong to the context that made them; a plan borrows its two
  * operands, which must stay alive until the plan is destroyed. */
 int         smm_device_count(void);              /* number of usable devices, 0 if none  */
 const char *smm_last_error(void);                /* thread-local message of the last failure */
-/* hip_stream: a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream),
- * or NULL for a stream the context creates and owns. */
+/* hip_stream: a hipStream_t to launch on, NULL for a non-blocking stream the context creates and
+ * owns, or SMM_STREAM_DEFAULT for the device's null stream (what torch's default stream is:
+ * torch.cuda.current_stream().cuda_stream == 0 -- pass SMM_STREAM_DEFAULT for it, not NULL).
+ * Device buffers handed to smm_csr_from_device must be complete on that stream (or the
+ * caller synchronises first): the library orders its work only against its own stream. */
+#define SMM_STREAM_DEFAULT ((void *)(intptr_t)-1)
 int  smm_ctx_create(int device, void *hip_stream, smm_ctx **out);
 void smm_ctx_destroy(smm_ctx *ctx);
 int  smm_ctx_synchronize(smm_ctx *ctx);

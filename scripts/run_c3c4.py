@@ -7,7 +7,7 @@ import time
 import torch
 
 sys.path.insert(0, ".")
-from bench import gen_csr_device  # noqa: E402
+from sparse_matrix_mult_amd.synthetic import gen_csr_device  # noqa: E402
 from sparse_matrix_mult_amd.engine import Context  # noqa: E402
 
 dev = torch.device("cuda", 0)

@@ -69,8 +69,10 @@ struct smm_ctx {
     std::vector<TimedLaunch> launches;
     std::map<std::string, std::pair<double, int64_t>> totals;
     unsigned *d_flags = nullptr;     // [0] validation flags; +64: int -1 and +128: double 0 read by idle lanes
-    std::mutex mu;
+    std::recursive_mutex mu;         // every entry point that touches the context takes it: calls from
+                                     // several host threads on one context serialise (one stream anyway)
 };
+#define CTX_LOCK(c) std::lock_guard<std::recursive_mutex> ctx_lock_((c)->mu)
 
 static int pool_alloc(smm_ctx *c, size_t bytes, void **out)
 {
@@ -161,7 +163,8 @@ extern "C" int smm_ctx_create(int device, void *hip_stream, smm_ctx **out)
     smm_ctx *c = new smm_ctx();
     c->device = device;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+    if (hip_stream == SMM_STREAM_DEFAULT) { c->stream = nullptr; c->own_stream = false; }   // the device's null stream
+    else if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
     else {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { delete c; return fail(SMM_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
@@ -198,6 +201,7 @@ extern "C" void smm_ctx_destroy(smm_ctx *c)
 extern "C" int smm_ctx_synchronize(smm_ctx *c)
 {
     if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CTX_LOCK(c);
     HIPCHK(hipStreamSynchronize(c->stream));
     return SMM_OK;
 }
@@ -219,6 +223,7 @@ static int drain_timers(smm_ctx *c)
 extern "C" int smm_ctx_timing(smm_ctx *c, int enable)
 {
     if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CTX_LOCK(c);
     CHK(drain_timers(c));
     c->timing = enable != 0;
     return SMM_OK;
@@ -226,6 +231,7 @@ extern "C" int smm_ctx_timing(smm_ctx *c, int enable)
 extern "C" int smm_ctx_timing_reset(smm_ctx *c)
 {
     if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CTX_LOCK(c);
     CHK(drain_timers(c));
     c->totals.clear();
     return SMM_OK;
@@ -233,6 +239,7 @@ extern "C" int smm_ctx_timing_reset(smm_ctx *c)
 extern "C" int smm_ctx_kernel_time(smm_ctx *c, const char *kernel, double *ms_total, int64_t *launches)
 {
     if (!c || !kernel) return fail(SMM_ERR_INVALID, "smm_ctx_kernel_time: NULL argument");
+    CTX_LOCK(c);
     CHK(drain_timers(c));
     auto it = c->totals.find(kernel);
     if (ms_total) *ms_total = it == c->totals.end() ? 0.0 : it->second.first;
@@ -242,6 +249,7 @@ extern "C" int smm_ctx_kernel_time(smm_ctx *c, const char *kernel, double *ms_to
 extern "C" int smm_ctx_tune(smm_ctx *c, int lds_cols, int waves)
 {
     if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CTX_LOCK(c);
     if (lds_cols) {
         if (lds_cols < 64 || lds_cols > 20000) return fail(SMM_ERR_INVALID, "lds_cols must be in [64,20000]");
         c->lds_cols = lds_cols;
@@ -256,6 +264,7 @@ extern "C" int smm_ctx_tune(smm_ctx *c, int lds_cols, int waves)
 extern "C" int smm_ctx_tune_hash(smm_ctx *c, int small_max, int medium_max)
 {
     if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CTX_LOCK(c);
     if (small_max < 0 || small_max > 256 || medium_max < 0 || medium_max > 2048)
         return fail(SMM_ERR_INVALID, "hash thresholds must be in [0,256] and [0,2048]");
     c->hash_small = small_max;
@@ -265,6 +274,7 @@ extern "C" int smm_ctx_tune_hash(smm_ctx *c, int small_max, int medium_max)
 extern "C" int smm_ctx_tune_shared(smm_ctx *c, int lds_cols, int waves)
 {
     if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CTX_LOCK(c);
     if (lds_cols) {
         if (lds_cols < 64 || lds_cols > 20000) return fail(SMM_ERR_INVALID, "lds_cols must be in [64,20000]");
         c->lds_cols_shared = lds_cols;
@@ -285,9 +295,13 @@ struct smm_csr {
     bool owned = false;
     bool validated = false;
     unsigned vflags = 0;
-    // cached tile index (sorted operands only)
-    int *seg = nullptr; int seg_wf = 0, seg_nft = 0;
-    short *loc = nullptr; int loc_wc = 0;      // tile-local columns for coarse width loc_wc
+    // cached tile indices (sorted operands only), one per tile geometry that has been asked for:
+    // plans keep the pointer of theirs, so a later product with another geometry (SMM_EXACT vs
+    // default, another tuning, the ELL chunks of the triple product) never invalidates it
+    struct SegCache { int wf, n_ft; int *seg; };
+    struct LocCache { int wc; short *loc; };          // tile-local columns for coarse width wc
+    std::vector<SegCache> segs;
+    std::vector<LocCache> locs;
     // sliced-ELL copy for triple-product stage 2 (chunk width ell_chunk)
     int ell_chunk = 0, ell_nchunks = 0; int *ell_len = nullptr; int64_t *ell_off = nullptr;
     short *ell_col = nullptr; double *ell_val = nullptr;
@@ -327,6 +341,7 @@ extern "C" int smm_csr_from_host(smm_ctx *c, int64_t rows, int64_t cols, int64_t
     if (!out) return fail(SMM_ERR_INVALID, "out is NULL");
     *out = nullptr;
     CHK(csr_common(c, rows, cols, nnz));
+    CTX_LOCK(c);
     if (!indptr || (nnz > 0 && (!indices || !data))) return fail(SMM_ERR_INVALID, "NULL CSR array");
     int *dp = nullptr, *di = nullptr; double *dv = nullptr;
     if (hipMalloc((void **)&dp, (rows + 1) * sizeof(int)) != hipSuccess ||
@@ -356,6 +371,7 @@ extern "C" int smm_csr_from_device(smm_ctx *c, int64_t rows, int64_t cols, int64
     if (!out) return fail(SMM_ERR_INVALID, "out is NULL");
     *out = nullptr;
     CHK(csr_common(c, rows, cols, nnz));
+    CTX_LOCK(c);
     if (!d_indptr || (nnz > 0 && (!d_indices || !d_data))) return fail(SMM_ERR_INVALID, "NULL CSR array");
     smm_csr *m = new smm_csr();
     m->ctx = c; m->rows = rows; m->cols = cols; m->nnz = nnz;
@@ -369,11 +385,12 @@ extern "C" int smm_csr_from_device(smm_ctx *c, int64_t rows, int64_t cols, int64
 extern "C" void smm_csr_destroy(smm_csr *m)
 {
     if (!m) return;
+    CTX_LOCK(m->ctx);
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     if (m->owned) { (void)hipFree((void *)m->ptr); (void)hipFree((void *)m->idx); (void)hipFree((void *)m->val); }
-    if (m->seg) (void)hipFree(m->seg);
-    if (m->loc) (void)hipFree(m->loc);
+    for (auto &e : m->segs) (void)hipFree(e.seg);
+    for (auto &e : m->locs) (void)hipFree(e.loc);
     (void)hipFree(m->ell_len); (void)hipFree(m->ell_off); (void)hipFree(m->ell_col); (void)hipFree(m->ell_val);
     delete m;
 }
@@ -383,6 +400,7 @@ extern "C" int64_t smm_csr_nnz(const smm_csr *m) { return m ? m->nnz : -1; }
 extern "C" int smm_csr_is_canonical(smm_ctx *c, smm_csr *m)
 {
     if (!c || !m) return fail(SMM_ERR_INVALID, "NULL argument");
+    CTX_LOCK(c);
     CHK(validate(c, m));
     return (m->vflags & (CSR_UNSORTED | CSR_HAS_EQUAL)) ? 0 : 1;
 }
@@ -422,35 +440,39 @@ static Geom make_geom(const smm_ctx *c, int64_t ncols, const smm_csr *b, bool ex
     return g;
 }
 
-static int ensure_seg(smm_ctx *c, smm_csr *b, const Geom &g)
+static int ensure_seg(smm_ctx *c, smm_csr *b, const Geom &g, const int **out)
 {
-    if (b->seg && b->seg_wf == g.wf && b->seg_nft == g.n_ft) return SMM_OK;
-    if (b->seg) { HIPCHK(hipStreamSynchronize(c->stream)); (void)hipFree(b->seg); b->seg = nullptr; }
+    for (auto &e : b->segs)
+        if (e.wf == g.wf && e.n_ft == g.n_ft) { *out = e.seg; return SMM_OK; }
     const int64_t total = b->rows * (int64_t)(g.n_ft + 1);
-    if (hipMalloc((void **)&b->seg, std::max<int64_t>(total, 1) * sizeof(int)) != hipSuccess)
+    int *seg = nullptr;
+    if (hipMalloc((void **)&seg, std::max<int64_t>(total, 1) * sizeof(int)) != hipSuccess)
         return fail(SMM_ERR_ALLOC, "hipMalloc of the tile index failed");
     if (total > 0) {
-        LAUNCH(c, "smm_segptr", smm_segptr, (total + 255) / 256, 256, 0, (int)b->rows, g.n_ft, g.wf, b->ptr, b->idx,
-               b->seg);
-        LAUNCH_CHECK();
+        LAUNCH(c, "smm_segptr", smm_segptr, (total + 255) / 256, 256, 0, (int)b->rows, g.n_ft, g.wf, b->ptr, b->idx, seg);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { (void)hipFree(seg); return fail(SMM_ERR_HIP, "smm_segptr: %s", hipGetErrorString(e)); }
     }
-    b->seg_wf = g.wf; b->seg_nft = g.n_ft;
+    b->segs.push_back({g.wf, g.n_ft, seg});
+    *out = seg;
     return SMM_OK;
 }
 
-static int ensure_loc(smm_ctx *c, smm_csr *b, const Geom &g)
+static int ensure_loc(smm_ctx *c, smm_csr *b, const Geom &g, const short **out)
 {
-    if (b->loc && b->loc_wc == g.wc) return SMM_OK;
+    for (auto &e : b->locs)
+        if (e.wc == g.wc) { *out = e.loc; return SMM_OK; }
     if (g.wc > 32767) return fail(SMM_ERR_INVALID, "coarse tile wider than 32767 columns");
-    if (b->loc) { HIPCHK(hipStreamSynchronize(c->stream)); (void)hipFree(b->loc); b->loc = nullptr; }
-    if (hipMalloc((void **)&b->loc, std::max<int64_t>(b->nnz, 1) * sizeof(short)) != hipSuccess)
+    short *loc = nullptr;
+    if (hipMalloc((void **)&loc, std::max<int64_t>(b->nnz, 1) * sizeof(short)) != hipSuccess)
         return fail(SMM_ERR_ALLOC, "hipMalloc of the tile-local column array failed");
     if (b->nnz > 0) {
-        LAUNCH(c, "smm_loc16", smm_loc16, std::min<int64_t>((b->nnz + 255) / 256, 65536), 256, 0, (int)b->nnz, g.wc, b->idx,
-               b->loc);
-        LAUNCH_CHECK();
+        LAUNCH(c, "smm_loc16", smm_loc16, std::min<int64_t>((b->nnz + 255) / 256, 65536), 256, 0, (int)b->nnz, g.wc, b->idx, loc);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { (void)hipFree(loc); return fail(SMM_ERR_HIP, "smm_loc16: %s", hipGetErrorString(e)); }
     }
-    b->loc_wc = g.wc;
+    b->locs.push_back({g.wc, loc});
+    *out = loc;
     return SMM_OK;
 }
 
@@ -462,7 +484,8 @@ static int ensure_ell(smm_ctx *c, smm_csr *h, int nchunks, int chunk)
     (void)hipFree(h->ell_len); (void)hipFree(h->ell_off); (void)hipFree(h->ell_col); (void)hipFree(h->ell_val);
     h->ell_len = nullptr; h->ell_off = nullptr; h->ell_col = nullptr; h->ell_val = nullptr; h->ell_chunk = 0;
     Geom gh; gh.nw = 1; gh.nct = nchunks; gh.wf = chunk; gh.wc = chunk; gh.n_ft = nchunks;
-    CHK(ensure_seg(c, h, gh));
+    const int *hseg = nullptr;
+    CHK(ensure_seg(c, h, gh, &hseg));
     const int n = (int)h->rows;
     const int nslices = (n + WAVE - 1) / WAVE;
     const int64_t items = (int64_t)nchunks * nslices;
@@ -475,7 +498,7 @@ static int ensure_ell(smm_ctx *c, smm_csr *h, int nchunks, int chunk)
     }
     EllArgs E{};
     E.n = n; E.nchunks = nchunks; E.chunk = chunk; E.nslices = nslices;
-    E.h_ptr = h->ptr; E.h_idx = h->idx; E.h_val = h->val; E.hseg = h->seg;
+    E.h_ptr = h->ptr; E.h_idx = h->idx; E.h_val = h->val; E.hseg = hseg;
     E.len = h->ell_len; E.cnt = cnt; E.off = h->ell_off;
     const int grid = (int)((items + 3) / 4);
     LAUNCH(c, "smm_ell_count", smm_ell_count, grid, 256, 0, E);
@@ -510,6 +533,8 @@ static int check_pair(smm_ctx *c, smm_csr *a, smm_csr *b)
 
 extern "C" int smm_row_products(smm_ctx *c, const smm_csr *a, const smm_csr *b, int64_t *products_host)
 {
+    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CTX_LOCK(c);
     CHK(check_pair(c, (smm_csr *)a, (smm_csr *)b));
     if (!products_host) return fail(SMM_ERR_INVALID, "products_host is NULL");
     if (a->rows == 0) return SMM_OK;
@@ -588,6 +613,8 @@ struct smm_plan {
     int *d_tmp = nullptr;          // capacity-strided ordered column lists
     unsigned *d_P = nullptr;       // nnz(A)
     unsigned *d_runs = nullptr;    // nnz(A) x (nct+1)
+    const int *seg = nullptr;      // B's tile index and tile-local columns for geometry g (owned by b)
+    const short *loc = nullptr;
     int *d_rowcnt = nullptr;       // m
     int *d_lists = nullptr;        // 3 x m: rows of the small / medium / dense bins
     int n_bin[3] = {0, 0, 0};
@@ -598,6 +625,7 @@ extern "C" void smm_plan_destroy(smm_plan *p)
 {
     if (!p) return;
     smm_ctx *c = p->ctx;
+    CTX_LOCK(c);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     pool_free(c, p->d_ub_off); pool_free(c, p->d_tmp); pool_free(c, p->d_P); pool_free(c, p->d_runs);
@@ -648,9 +676,10 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
 {
     if (!plan) return fail(SMM_ERR_INVALID, "plan is NULL");
     *plan = nullptr;
+    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CTX_LOCK(c);
     CHK(check_pair(c, a, b));
     if (a_row_offset < 0) return fail(SMM_ERR_INVALID, "negative a_row_offset");
-    std::lock_guard<std::mutex> lock(c->mu);
     smm_plan *p = new smm_plan();
     p->ctx = c; p->a = a; p->b = b; p->flags = flags; p->row_offset = a_row_offset;
     p->m = a->rows; p->ncols = b->cols;
@@ -782,8 +811,8 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "row binning: %s", hipGetErrorString(e)); }
     }
     if (p->b_sorted && p->n_bin[2] > 0) {
-        PCHK(ensure_seg(c, b, p->g));
-        PCHK(ensure_loc(c, b, p->g));
+        PCHK(ensure_seg(c, b, p->g, &p->seg));
+        PCHK(ensure_loc(c, b, p->g, &p->loc));
         PCHK(pool_get(c, (size_t)a->nnz * (p->g.nct + 1), &p->d_runs));
         const int nd = p->n_bin[2];
         const int rgrid = (int)std::min<int64_t>((nd + 3) / 4, 65536);
@@ -803,7 +832,7 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
     if (!c || !p || p->ctx != c) return fail(SMM_ERR_INVALID, "bad plan/context");
     if (!d_c_indptr) return fail(SMM_ERR_INVALID, "d_c_indptr is NULL");
     HIPCHK(hipSetDevice(c->device));
-    std::lock_guard<std::mutex> lock(c->mu);
+    CTX_LOCK(c);
     const int64_t m = p->m;
     HIPCHK(hipMemcpyAsync(d_c_indptr, p->d_cptr, (m + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
     if (p->nnz == 0) return SMM_OK;
@@ -848,7 +877,7 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
         A.row_offset = p->row_offset;
         A.rowlist = dense_rows;
         A.a_ptr = p->a->ptr; A.a_idx = p->a->idx; A.a_val = p->a->val;
-        A.b_idx = p->b->idx; A.b_val = p->b->val; A.seg = p->b->seg; A.b_loc = p->b->loc;
+        A.b_idx = p->b->idx; A.b_val = p->b->val; A.seg = p->seg; A.b_loc = p->loc;
         A.c_ptr = p->d_cptr; A.c_idx = d_c_indices; A.c_val = d_c_data;
         A.ub_off = p->d_ub_off; A.tmp_idx = p->d_tmp; A.runs = p->d_runs;
         CHK(launch_numeric<OUT_SPARSE>(c, A, sym, p->g.nw, exact));
@@ -878,6 +907,7 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
 extern "C" int smm_plan_indptr_host(smm_ctx *c, smm_plan *p, int64_t *c_indptr)
 {
     if (!c || !p || !c_indptr) return fail(SMM_ERR_INVALID, "NULL argument");
+    CTX_LOCK(c);
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(c_indptr, p->d_cptr, (p->m + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -887,6 +917,7 @@ extern "C" int smm_plan_indptr_host(smm_ctx *c, smm_plan *p, int64_t *c_indptr)
 extern "C" int smm_spgemm_numeric_host(smm_ctx *c, smm_plan *p, int64_t *c_indptr, int32_t *c_indices, double *c_data)
 {
     if (!c || !p || !c_indptr) return fail(SMM_ERR_INVALID, "NULL argument");
+    CTX_LOCK(c);
     HIPCHK(hipSetDevice(c->device));
     int64_t *dp = nullptr; int *di = nullptr; double *dv = nullptr;
     const int64_t nnz = p->nnz;
@@ -923,13 +954,14 @@ static int dense_into(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t row
     }
     if (!(b->vflags & CSR_UNSORTED)) {
         Geom g = make_geom(c, n, b, (flags & SMM_EXACT) != 0);
-        CHK(ensure_seg(c, b, g));
-        CHK(ensure_loc(c, b, g));
+        const int *seg = nullptr; const short *loc = nullptr;
+        CHK(ensure_seg(c, b, g, &seg));
+        CHK(ensure_loc(c, b, g, &loc));
         NumericArgs A{};
         A.m = (int)m; A.ncols = (int)n; A.nct = g.nct; A.wc = g.wc; A.wf = g.wf; A.n_ft = g.n_ft;
         A.row_offset = row_offset;
         A.a_ptr = a->ptr; A.a_idx = a->idx; A.a_val = a->val;
-        A.b_idx = b->idx; A.b_val = b->val; A.seg = b->seg; A.b_loc = b->loc;
+        A.b_idx = b->idx; A.b_val = b->val; A.seg = seg; A.b_loc = loc;
         A.c_dense = d_c; A.ldc = ldc;
         CHK(launch_numeric<OUT_DENSE>(c, A, sym, g.nw, (flags & SMM_EXACT) != 0));
     } else {
@@ -947,14 +979,17 @@ static int dense_into(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t row
 
 extern "C" int smm_spgemm_dense(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t a_row_offset, double *d_c)
 {
+    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CTX_LOCK(c);
     CHK(check_pair(c, a, b));
     if (!d_c && a->rows * b->cols > 0) return fail(SMM_ERR_INVALID, "d_c is NULL");
-    std::lock_guard<std::mutex> lock(c->mu);
     return dense_into(c, a, b, flags, a_row_offset, d_c, b->cols);
 }
 
 extern "C" int smm_spgemm_dense_host(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t a_row_offset, double *out)
 {
+    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CTX_LOCK(c);
     CHK(check_pair(c, a, b));
     const int64_t total = a->rows * b->cols;
     if (total == 0) return SMM_OK;
@@ -976,9 +1011,13 @@ extern "C" int smm_spgemm_dense_host(smm_ctx *c, smm_csr *a, smm_csr *b, int fla
 extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags, int64_t row_begin, int64_t row_end,
                                   double *d_c)
 {
+    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CTX_LOCK(c);
     CHK(check_pair(c, h, q));
-    if (q->rows != q->cols) return fail(SMM_ERR_INVALID, "Q must be square (K x K)");
     const int64_t n = h->rows, K = h->cols;
+    // the reference indexes temp_values[K] with Q's columns (sparse_sparse_dense.cpp:178,196): Q may
+    // be K x c with c <= K (columns c..K-1 of T stay 0); c > K would write out of bounds there
+    if (q->cols > K) return fail(SMM_ERR_INVALID, "Q has more columns (%lld) than H (%lld)", (long long)q->cols, (long long)K);
     if (row_begin < 0 || row_end > n || row_begin > row_end) return fail(SMM_ERR_INVALID, "bad row range");
     const bool full = flags & SMM_FULL_MATRIX;
     if (full && (row_begin != 0 || row_end != n))
@@ -986,9 +1025,6 @@ extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags,
     const int64_t nr = row_end - row_begin;
     if (nr == 0 || n == 0) return SMM_OK;
     if (!d_c) return fail(SMM_ERR_INVALID, "d_c is NULL");
-    if (h->vflags & CSR_UNSORTED)
-        return fail(SMM_ERR_INVALID, "triple product needs H with sorted column indices inside each row");
-    std::lock_guard<std::mutex> lock(c->mu);
     if (h->nnz == 0 || q->nnz == 0 || K == 0) {
         HIPCHK(hipMemset2DAsync(d_c, n * sizeof(double), 0, n * sizeof(double), nr, c->stream));
         return SMM_OK;
@@ -996,12 +1032,29 @@ extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags,
     // stage 1: T = H[row_begin:row_end, :] * Q, dense nr x K (sparse_sparse_dense.cpp:187-198)
     double *T = nullptr;
     CHK(pool_get(c, (size_t)nr * K, &T));
+    if (q->cols < K) HIPCHK(hipMemsetAsync(T, 0, (size_t)nr * K * sizeof(double), c->stream));
     smm_csr hv = *h;                       // row-range view of H (borrowed arrays)
-    hv.ptr = h->ptr + row_begin; hv.rows = nr; hv.owned = false; hv.seg = nullptr; hv.loc = nullptr;
+    hv.ptr = h->ptr + row_begin; hv.rows = nr; hv.owned = false; hv.segs.clear(); hv.locs.clear();
     // indptr of the view is not rebased: kernels only use ptr[row], ptr[row+1] as absolute positions.
     int rc = dense_into(c, &hv, q, flags & SMM_EXACT, 0, T, K);
     if (rc != SMM_OK) { pool_free(c, T); return rc; }
     // stage 2
+    if (h->vflags & CSR_UNSORTED) {
+        // H with unsorted rows (legal CSR, e.g. an unsorted scipy product): the chunked ELL walk needs
+        // sorted rows, so every (i,k) sums row k of H in its stored order, as the reference does
+        dim3 grid((unsigned)((n + 255) / 256), (unsigned)std::min<int64_t>(nr, 65535));
+        {
+            LaunchTimer lt_(c, "smm_triple_stage2_general");
+            hipLaunchKernelGGL(smm_triple_stage2_general, grid, dim3(256), 0, c->stream, (int)n, (int)K, row_begin, row_end,
+                               full ? 1 : 0, h->ptr, h->idx, h->val, (const double *)T, d_c, n);
+        }
+        if (full) LAUNCH(c, "smm_triple_mirror", smm_triple_mirror, (n * n + 255) / 256, 256, 0, (int)n, d_c, n);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        pool_free(c, T);
+        if (e != hipSuccess) return fail(SMM_ERR_HIP, "triple product: %s", hipGetErrorString(e));
+        return SMM_OK;
+    }
     constexpr int NW = 16;
     constexpr int R = 16;
     const int chunk_cap = 1024;            // [chunk][R+2] f64 = 144 KB of LDS
@@ -1035,6 +1088,7 @@ extern "C" int smm_triple_product_host(smm_ctx *c, smm_csr *h, smm_csr *q, int f
                                        int64_t row_end, double *out)
 {
     if (!c || !h || !q) return fail(SMM_ERR_INVALID, "NULL argument");
+    CTX_LOCK(c);
     const int64_t n = h->rows, nr = row_end - row_begin;
     if (nr <= 0 || n == 0) return smm_triple_product(c, h, q, flags, row_begin, row_end, nullptr);
     if (!out) return fail(SMM_ERR_INVALID, "c is NULL");
@@ -1055,6 +1109,7 @@ extern "C" int smm_triple_product_host(smm_ctx *c, smm_csr *h, smm_csr *q, int f
 extern "C" int smm_device_malloc(smm_ctx *c, int64_t bytes, void **d_ptr)
 {
     if (!c || !d_ptr || bytes < 0) return fail(SMM_ERR_INVALID, "bad argument");
+    CTX_LOCK(c);
     HIPCHK(hipSetDevice(c->device));
     hipError_t e = hipMalloc(d_ptr, (size_t)std::max<int64_t>(bytes, 16));
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(SMM_ERR_ALLOC, "hipMalloc(%lld): %s", (long long)bytes, hipGetErrorString(e)); }
@@ -1063,6 +1118,7 @@ extern "C" int smm_device_malloc(smm_ctx *c, int64_t bytes, void **d_ptr)
 extern "C" int smm_device_free(smm_ctx *c, void *d_ptr)
 {
     if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CTX_LOCK(c);
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipFree(d_ptr));
@@ -1072,6 +1128,7 @@ extern "C" int smm_memcpy_d2h(smm_ctx *c, void *dst, const void *src, int64_t by
 {
     if (!c || bytes < 0) return fail(SMM_ERR_INVALID, "bad argument");
     if (bytes == 0) return SMM_OK;
+    CTX_LOCK(c);
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1081,6 +1138,7 @@ extern "C" int smm_memcpy_h2d(smm_ctx *c, void *dst, const void *src, int64_t by
 {
     if (!c || bytes < 0) return fail(SMM_ERR_INVALID, "bad argument");
     if (bytes == 0) return SMM_OK;
+    CTX_LOCK(c);
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -1388,6 +1388,25 @@ __global__ __launch_bounds__(NW * 64) void smm_triple_stage2(const TripleArgs A)
     }
 }
 
+// Stage 2 for an H whose rows are not sorted: one thread per (i, k), the reference's scalar loop
+// (sparse_sparse_dense.cpp:203-211) in H's stored order.  Correctness path, not a fast path.
+__global__ __launch_bounds__(256) void smm_triple_stage2_general(int n, int K, int64_t row_begin, int64_t row_end, int full,
+                                                                 const int *__restrict__ h_ptr, const int *__restrict__ h_idx,
+                                                                 const double *__restrict__ h_val, const double *__restrict__ T,
+                                                                 double *__restrict__ C, int64_t ldc)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int s = h_ptr[k], e = h_ptr[k + 1];
+    for (int64_t i = row_begin + blockIdx.y; i < row_end; i += gridDim.y) {
+        const double *t = T + (i - row_begin) * K;
+        double sum = 0.0;
+        if (full || k >= i)
+            for (int jp = s; jp < e; ++jp) sum += t[h_idx[jp]] * h_val[jp];
+        C[(i - row_begin) * ldc + k] = sum;
+    }
+}
+
 // compute_full_matrix=1 (sparse_sparse_dense.cpp:212-215): cell (a,b), a != b, receives
 // S[min,max] first and S[max,min] second; the diagonal receives S[a,a] once.  In place on
 // the full S: each thread owns one unordered pair.

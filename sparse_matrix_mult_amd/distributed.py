@@ -21,7 +21,8 @@ world_size 2, in tests/test_distributed_cpu.py).
 """
 import numpy as np
 
-__all__ = ["balanced_row_shards", "global_indptr", "allgatherv", "allgather_csr", "spgemm_row_sharded"]
+__all__ = ["balanced_row_shards", "row_work", "triple_row_shards", "global_indptr", "allgatherv", "allgather_csr",
+           "allgather_rows", "spgemm_row_sharded", "dense_row_sharded", "triple_row_sharded"]
 
 
 def balanced_row_shards(work, n_shards):
@@ -43,6 +44,15 @@ def balanced_row_shards(work, n_shards):
         bounds.append(cut)
     bounds.append(rows)
     return [(bounds[i], bounds[i + 1]) for i in range(n)]
+
+
+def row_work(a_indptr, a_indices, b_row_len):
+    """products per row of A: sum of nnz(B[r,:]) over the row's entries, from the structure alone
+    (prefix-sum difference: empty rows anywhere, trailing ones included, give 0)."""
+    per_entry = np.asarray(b_row_len, dtype=np.int64)[np.asarray(a_indices)]
+    cs = np.concatenate([[0], np.cumsum(per_entry, dtype=np.int64)])
+    ptr = np.asarray(a_indptr, dtype=np.int64)
+    return cs[ptr[1:]] - cs[ptr[:-1]]
 
 
 def _world(dist, group=None):
@@ -135,10 +145,7 @@ def spgemm_row_sharded(ctx, matrix_a, matrix_b, dist, symmetric=False, gather=Tr
     try:
         # work per row from the structure alone: sum of nnz(B[r,:]) over A's entries
         b_len = np.diff(matrix_b.indptr).astype(np.int64)
-        per_entry = b_len[matrix_a.indices]
-        work = np.add.reduceat(per_entry, matrix_a.indptr[:-1].astype(np.int64)) if matrix_a.nnz else \
-            np.zeros(matrix_a.shape[0])
-        work = np.where(np.diff(matrix_a.indptr) > 0, work, 0)
+        work = row_work(matrix_a.indptr, matrix_a.indices, b_len)
         shards = balanced_row_shards(work, world)
         r0, r1 = shards[rank] if rank < len(shards) else (matrix_a.shape[0], matrix_a.shape[0])
         a = ctx.csr_from_scipy(matrix_a[r0:r1])
@@ -151,3 +158,89 @@ def spgemm_row_sharded(ctx, matrix_a, matrix_b, dist, symmetric=False, gather=Tr
     if gather:
         return allgather_csr(indptr, indices, data, dist, group)
     return global_indptr(indptr, dist, group), (r0, r1), indices, data
+
+
+def triple_row_shards(n, n_shards, full=False):
+    """Row blocks of the n x n triple product balanced by the work of stage 2: row i computes the
+    cells k >= i, i.e. n - i of them (all n with compute_full_matrix) -- the reference hands rows
+    out with schedule(dynamic, 64) for the same reason (src/sparse_sparse_dense.cpp:183)."""
+    i = np.arange(n, dtype=np.float64)
+    return balanced_row_shards(np.full(n, float(n)) if full else (n - i), n_shards)
+
+
+def allgather_rows(local, rows_per_rank, dist, group=None):
+    """All-gather of a row-sharded dense matrix: `local` is this rank's (rows_r x n) block; the
+    blocks are padded to the tallest one so that ONE plain all_gather_into_tensor (RCCL's native
+    all-gather; equal tiles, SURVEY 8e "Dense output") moves them, then the padding is dropped.
+    Returns the (sum(rows) x n) matrix on every rank."""
+    import torch
+    world, rank = _world(dist, group)
+    rows_per_rank = [int(r) for r in rows_per_rank]
+    assert len(rows_per_rank) == world and local.shape[0] == rows_per_rank[rank]
+    n = int(local.shape[1])
+    tall = max(rows_per_rank) if rows_per_rank else 0
+    send, back = _stage(local.contiguous(), dist, group)
+    if send.shape[0] < tall:
+        pad = torch.zeros((tall - send.shape[0], n), dtype=send.dtype, device=send.device)
+        send = torch.cat([send, pad], 0)
+    out = torch.empty((world * tall, n), dtype=send.dtype, device=send.device)
+    if tall * n > 0:
+        dist.all_gather_into_tensor(out, send, group=group)
+    if any(r != tall for r in rows_per_rank):
+        out = torch.cat([out[r * tall:r * tall + rows_per_rank[r]] for r in range(world)], 0)
+    return out.to(back) if back is not None else out
+
+
+def _shard_rows(shards, world):
+    return [(shards[r][1] - shards[r][0]) if r < len(shards) else 0 for r in range(world)]
+
+
+def dense_row_sharded(ctx, matrix_a, matrix_b, dist, symmetric=False, gather=True, group=None, exact=False):
+    """C = A @ B as a dense matrix, A's rows sharded over the ranks (dense_nosym / dense_sym run
+    their rows under `omp parallel for`, src/sparse_sparse_dense.cpp:38,106).  Returns the whole
+    m x n torch tensor on every rank (gather=True), else ((row_begin, row_end), local block)."""
+    import torch
+    world, rank = _world(dist, group)
+    m, n = matrix_a.shape[0], matrix_b.shape[1]
+    work = row_work(matrix_a.indptr, matrix_a.indices, np.diff(matrix_b.indptr))
+    shards = balanced_row_shards(work, world)
+    r0, r1 = shards[rank] if rank < len(shards) else (m, m)
+    dev = torch.device("cuda", ctx.device)
+    local = torch.empty((r1 - r0, n), dtype=torch.float64, device=dev)
+    if r1 > r0 and n > 0:
+        b = ctx.csr_from_scipy(matrix_b)
+        try:
+            a = ctx.csr_from_scipy(matrix_a[r0:r1])
+            try:
+                ctx.dense_into(a, b, local.data_ptr(), symmetric=symmetric, row_offset=r0, exact=exact)
+                ctx.synchronize()
+            finally:
+                a.close()
+        finally:
+            b.close()
+    if not gather:
+        return (r0, r1), local
+    return allgather_rows(local, _shard_rows(shards, world), dist, group)
+
+
+def triple_row_sharded(ctx, matrix_h, matrix_q, dist, gather=True, group=None, exact=False):
+    """Upper triangle of H Q H^T (compute_full_matrix=0, the BASELINE configuration) with the rows
+    of the result sharded over the ranks, blocks balanced by sum(n - i); H and Q are replicated
+    (stage 2 reads all of H).  Returns the n x n tensor on every rank, else ((r0, r1), block)."""
+    import torch
+    world, rank = _world(dist, group)
+    n = matrix_h.shape[0]
+    shards = triple_row_shards(n, world)
+    r0, r1 = shards[rank] if rank < len(shards) else (n, n)
+    dev = torch.device("cuda", ctx.device)
+    local = torch.empty((r1 - r0, n), dtype=torch.float64, device=dev)
+    if r1 > r0:
+        h, q = ctx.csr_from_scipy(matrix_h), ctx.csr_from_scipy(matrix_q)
+        try:
+            ctx.triple_into(h, q, local.data_ptr(), row_begin=r0, row_end=r1, exact=exact)
+            ctx.synchronize()
+        finally:
+            h.close(); q.close()
+    if not gather:
+        return (r0, r1), local
+    return allgather_rows(local, _shard_rows(shards, world), dist, group)

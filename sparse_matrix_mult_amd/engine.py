@@ -24,15 +24,25 @@ def _ptr(arr):
 
 
 class Context:
-    """One GPU + one stream + pooled workspace (smm_ctx).  `stream` may be a raw hipStream_t
-    (int), e.g. torch.cuda.current_stream().cuda_stream; None lets the library create one."""
+    """One GPU + one stream + pooled workspace (smm_ctx).  `stream`: None lets the library create
+    (and own) a non-blocking stream; a raw hipStream_t (int) makes it launch there, e.g.
+    torch.cuda.current_stream().cuda_stream -- whose value 0 means torch's default stream, i.e.
+    the device's null stream (SMM_STREAM_DEFAULT), NOT "create one".  Calls from several host
+    threads on one context are safe: the library serialises them on the context's lock."""
 
     def __init__(self, device=0, stream=None):
         self.lib = SmmLibrary().get_lib()
         h = ctypes.c_void_p()
-        check(self.lib, self.lib.smm_ctx_create(int(device), ctypes.c_void_p(stream or 0), ctypes.byref(h)))
+        if stream is None:
+            raw = 0                                   # NULL: the context creates its own stream
+        elif int(stream) == 0:
+            raw = ctypes.c_void_p(-1).value           # SMM_STREAM_DEFAULT: the null stream
+        else:
+            raw = int(stream)
+        check(self.lib, self.lib.smm_ctx_create(int(device), ctypes.c_void_p(raw), ctypes.byref(h)))
         self.handle = h
         self.device = int(device)
+        self.stream = None if stream is None else int(stream)     # None = private stream
 
     def close(self):
         if getattr(self, "handle", None):
@@ -90,7 +100,13 @@ class Context:
         return DeviceCSR(self, h, rows, cols, nnz)
 
     def csr_from_torch(self, rows, cols, indptr, indices, data):
-        """Borrow int32/int32/float64 CUDA tensors already in HBM (kept alive by the handle)."""
+        """Borrow int32/int32/float64 CUDA tensors already in HBM (kept alive by the handle).  The
+        tensors must be complete before the library reads them: when the context does not launch on
+        torch's current stream, that stream is synchronised here."""
+        import torch
+        cur = torch.cuda.current_stream(indices.device)
+        if self.stream is None or int(cur.cuda_stream) != self.stream:
+            cur.synchronize()
         nnz = int(indices.numel())
         h = ctypes.c_void_p()
         check(self.lib, self.lib.smm_csr_from_device(self.handle, rows, cols, nnz, ctypes.c_void_p(indptr.data_ptr()),

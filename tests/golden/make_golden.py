@@ -27,6 +27,7 @@ duplicated inputs, empty rows).
 """
 import os
 import sys
+import zlib
 
 import numpy as np
 import scipy.sparse as sp
@@ -101,7 +102,7 @@ TRIPLE = {   # H (n x k), Q (k x k, symmetric as BASELINE config 4)
 }
 
 
-def main():
+def main(path=None):
     assert rb.available(), "run `make -C oracle ref` first"
     out = {}
     for name, (a, b) in CASES.items():
@@ -127,7 +128,7 @@ def main():
         assert np.array_equal(sp.csr_matrix((v, i, p), shape=(m, n)).toarray(), out[f"{name}/ref_dense"]), name
     for name, (h, _) in TRIPLE.items():
         n, k = h[0]
-        s = sp.random(k, k, density=0.05, format="csr", random_state=np.random.default_rng(hash(name) % 1000))
+        s = sp.random(k, k, density=0.05, format="csr", random_state=np.random.default_rng(zlib.crc32(name.encode()) % 1000))
         q = csr((s + s.T).tocsr())
         out[f"{name}/h_shape"] = np.array(h[0], np.int64)
         out[f"{name}/h_indptr"], out[f"{name}/h_indices"], out[f"{name}/h_data"] = h[1:]
@@ -137,7 +138,7 @@ def main():
     for rows, procs in ((10, 3), (3, 8), (100, 7), (16, 16), (1, 1), (50000, 8)):
         p, arr = rb.limits(rows, procs)
         out[f"limits/{rows}_{procs}"] = np.concatenate([[p], arr]).astype(np.int64)
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_vectors.npz")
+    path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_vectors.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
 

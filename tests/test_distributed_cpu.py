@@ -21,20 +21,27 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, symmetric, ret):
+def _worker(rank, world, port, symmetric, empty_rows, ret):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
     import torch.distributed as dist
     from oracle import oracle
-    from sparse_matrix_mult_amd.distributed import allgather_csr, balanced_row_shards, global_indptr
+    from sparse_matrix_mult_amd.distributed import allgather_csr, balanced_row_shards, global_indptr, row_work
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         A, B = rand_csr(203, 150, 0.06, 1), rand_csr(150, 203, 0.06, 2)
+        if empty_rows:              # leading, interior and trailing empty rows of A (reduceat raised there)
+            A = A.tolil()
+            for r in (0, 1, 57, 58, 59, 201, 202):
+                A[r, :] = 0
+            A = A.tocsr()
+            A.eliminate_zeros()
         a, b = arrays(A), arrays(B)
-        work = np.add.reduceat(np.diff(b[0])[a[1]], a[0][:-1]) * (np.diff(a[0]) > 0)
+        work = row_work(a[0], a[1], np.diff(b[0]))
+        assert work.shape == (203,) and (work[np.diff(a[0]) == 0] == 0).all()
         shards = balanced_row_shards(work, world)
         r0, r1 = shards[rank]
         cnt, idx, val = oracle.sparse_rows(a, b, 203, r0, r1, symmetric=symmetric)
@@ -54,12 +61,62 @@ def _worker(rank, world, port, symmetric, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("symmetric", [False, True])
-def test_row_sharded_allgatherv_reassembles_single_device_csr(world, symmetric):
+@pytest.mark.parametrize("world,symmetric,empty_rows", [(2, False, False), (2, True, True), (3, False, True), (3, True, False)])
+def test_row_sharded_allgatherv_reassembles_single_device_csr(world, symmetric, empty_rows):
     import torch.multiprocessing as mp
     port = _free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker, args=(world, port, symmetric, ret), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, symmetric, empty_rows, ret), nprocs=world, join=True)
+        assert dict(ret) == {r: True for r in range(world)}
+
+
+def _dense_worker(rank, world, port, ret):
+    """dense_row_sharded / triple_row_sharded without a GPU: the oracle computes each rank's row
+    block, allgather_rows (padded equal tiles, one all_gather_into_tensor) reassembles it."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scipy.sparse as sp
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle
+    from sparse_matrix_mult_amd.distributed import (allgather_rows, balanced_row_shards, row_work,
+                                                    triple_row_shards, _shard_rows)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        A, B = rand_csr(61, 40, 0.1, 3), rand_csr(40, 61, 0.1, 4)
+        a, b = arrays(A), arrays(B)
+        ok = True
+        for symmetric in (False, True):
+            shards = balanced_row_shards(row_work(a[0], a[1], np.diff(b[0])), world)
+            r0, r1 = shards[rank]
+            blk = oracle.dense(a, b, 61, symmetric=symmetric, row_begin=r0, row_end=r1)
+            full = allgather_rows(torch.from_numpy(blk), _shard_rows(shards, world), dist).numpy()
+            ok &= np.array_equal(full, oracle.dense(a, b, 61, symmetric=symmetric))
+        S = sp.random(40, 40, density=0.1, format="csr", random_state=np.random.default_rng(5))
+        q = arrays((S + S.T).tocsr())
+        shards = triple_row_shards(61, world)
+        r0, r1 = shards[rank]
+        blk = oracle.triple(a, q, 40, 0, r0, r1)[r0:r1]
+        full = allgather_rows(torch.from_numpy(np.ascontiguousarray(blk)), _shard_rows(shards, world), dist).numpy()
+        ok &= np.array_equal(full, oracle.triple(a, q, 40, 0))
+        # more ranks than rows: the trailing ranks hold empty blocks
+        tiny = triple_row_shards(1, world)
+        rows = _shard_rows(tiny, world)
+        mine = torch.full((rows[rank], 3), float(rank))
+        ok &= allgather_rows(mine, rows, dist).shape == (1, 3)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_dense_and_triple_row_blocks_allgather(world):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_dense_worker, args=(world, port, ret), nprocs=world, join=True)
         assert dict(ret) == {r: True for r in range(world)}

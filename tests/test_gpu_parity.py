@@ -312,3 +312,61 @@ def test_malformed_operand_is_rejected(ctx):
     with pytest.raises(SmmError):
         ctx.spgemm_host(A, B)
     A.close(); B.close()
+
+
+def test_plans_of_both_modes_on_one_b_run_in_any_order(ctx, oracle):
+    """the tile index lives on the operand; a plan keeps ITS geometry's index, so an
+    SMM_EXACT plan and a default plan on the same B (plus a dense product and a triple product
+    with other geometries in between) may run their numeric phases in any order."""
+    import ctypes
+    A, B = rand_csr(400, 300, 0.05, 1), rand_csr(300, 30000, 0.01, 2)
+    want = oracle.sparse(arrays(A), arrays(B), 30000)
+    a, b = ctx.csr_from_scipy(A), ctx.csr_from_scipy(B)
+    ctx.tune_hash(0, 0)                                   # every row through the tile kernels
+    try:
+        p_exact = ctx.spgemm_plan(a, b, exact=True)
+        p_deflt = ctx.spgemm_plan(a, b, exact=False)
+        ctx.dense_host(a, b, exact=True)                  # both geometries touched again
+        ctx.tune(9000, 4)                                 # a third one for later plans
+        p_third = ctx.spgemm_plan(a, b, exact=True)
+        ctx.tune(18000, 8)
+        for plan, values in ((p_deflt, "tol"), (p_exact, "bits"), (p_third, "bits")):   # not the creation order
+            indptr = np.empty(a.rows + 1, np.int64)
+            indices, data = np.empty(plan.nnz, np.int32), np.empty(plan.nnz, np.float64)
+            from sparse_matrix_mult_amd._lib import check
+            check(ctx.lib, ctx.lib.smm_spgemm_numeric_host(ctx.handle, plan.handle, ctypes.c_void_p(indptr.ctypes.data),
+                                                           ctypes.c_void_p(indices.ctypes.data),
+                                                           ctypes.c_void_p(data.ctypes.data)))
+            assert_csr_equal((indptr, indices, data), want, values=values, rtol=RTOL)
+        for p in (p_exact, p_deflt, p_third):
+            p.close()
+    finally:
+        ctx.tune_hash(256, 2048)
+        a.close(); b.close()
+
+
+@pytest.mark.parametrize("full", [False, True])
+def test_triple_unsorted_h_and_narrow_q(ctx, oracle, full):
+    """The reference's triple_product sums in H's stored order whatever it is and only needs Q's
+    columns to fit temp_values[K] (src/sparse_sparse_dense.cpp:178-212): an H with unsorted rows
+    and a K x c Q with c < K are legal."""
+    H = shuffle_rows(rand_csr(90, 150, 0.08, 3), 4)
+    S = sp.random(150, 150, density=0.04, format="csr", random_state=np.random.default_rng(5))
+    Q = (S + S.T).tocsr()
+    Qn = Q[:, :100].tocsr()                                # 150 x 100
+    for q in (Q, Qn):
+        want = oracle.triple(arrays(H), arrays(q), 150, int(full))
+        h, qd = ctx.csr_from_scipy(H), ctx.csr_from_scipy(q)
+        try:
+            got = ctx.triple_host(h, qd, full=full, exact=True)
+        finally:
+            h.close(); qd.close()
+        assert np.array_equal(got.view(np.int64), want.view(np.int64))
+    Hs = rand_csr(90, 150, 0.08, 3)                        # sorted H, narrow Q: the ELL path
+    want = oracle.triple(arrays(Hs), arrays(Qn), 150, int(full))
+    h, qd = ctx.csr_from_scipy(Hs), ctx.csr_from_scipy(Qn)
+    try:
+        got = ctx.triple_host(h, qd, full=full, exact=True)
+    finally:
+        h.close(); qd.close()
+    assert np.array_equal(got.view(np.int64), want.view(np.int64))
