@@ -6,7 +6,7 @@ The distribution is scipy.sparse.random's (uniform[0,1) float64 value
 column indices): every cell is kept with probability `density`, so row lengths are binomial --
 scipy's are hypergeometric with the same mean, indistinguishable at these sizes.  The random
 STREAM differs from scipy's, which is why parity at these sizes is always checked on the very
-arrays generated here, handed to the CPU oracle (tests/test_gpu_baseline_configs.py)."""
+arrays generated here (tests/test_gpu_baseline_configs.py)."""
 
 __all__ = ["gen_csr_device", "gen_symmetric_csr_device"]
 

@@ -15,6 +15,7 @@ HEADER = os.path.join(ROOT, "include", "smm_hip.h")
 def _declared_functions():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"^[ \t]*#.*$", "", text, flags=re.M)          # preprocessor lines (macros are not symbols)
     names = re.findall(r"\b(\w+)\s*\([^;{}]*\)\s*;", text)
     return sorted(set(n for n in names if not n.startswith("__")))
 
