@@ -6,8 +6,10 @@ Unlike the reference it is silent at import (SURVEY F9 / section 8b "Side effect
 refuses to run without the HIP library: there is no CPU fallback in this package.
 """
 import ctypes
+import importlib.util
 import os
 import subprocess
+import sys
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -85,6 +87,30 @@ def build(force=False):
     subprocess.run(args, check=True)
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same
+    SONAME as /opt/rocm's, which libsmm_hip.so links).  When torch is imported FIRST the dynamic
+    linker hands that copy to this library too and device pointers are interchangeable
+    (csr_from_torch, spgemm_torch, bench.py).  In the other order the process would hold two
+    runtimes and the second one finds no device -- so, when torch is installed but not yet
+    imported, its copy is loaded here first (no `import torch`: only the shared object).
+    SMM_HIP_RUNTIME=system keeps /opt/rocm's runtime (a process that will never import torch)."""
+    if "torch" in sys.modules or os.environ.get("SMM_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 class SmmLibrary:
     """Singleton holding the loaded library (reference MatrixOpsLibrary, matrix_ops.py:51-72)."""
     _instance = None
@@ -104,6 +130,7 @@ class SmmLibrary:
                 raise OSError(
                     f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                     "or `make -C sparse_matrix_mult_amd/csrc`. This package has no CPU fallback.")
+            _share_hip_runtime_with_torch()
             lib = ctypes.CDLL(LIB_PATH)
             for name, (res, args) in V2_PROTOTYPES.items():
                 fn = getattr(lib, name)
