@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--lds-cols", type=int, default=0)
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--hash", type=str, default="", help="small,medium thresholds of the LDS-hash kernels (0,0 = off)")
+    ap.add_argument("--slab", type=str, default="", help="mode,ws,rows_per_wave of the row-block x column-slab kernels "
+                                                         "(mode 0 auto / 1 off / 2 force; ws 0 = L2-sized)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -164,6 +166,8 @@ def main():
         (ctx.tune if args.exact else ctx.tune_shared)(args.lds_cols, args.waves)
     if args.hash:
         ctx.tune_hash(*[int(x) for x in args.hash.split(",")])
+    if args.slab:
+        ctx.tune_slab(*[int(x) for x in args.slab.split(",")])
 
     cfg = args.config
     if cfg == "c3":
@@ -273,7 +277,7 @@ def main():
             for name in ("traffic_r2.json", "traffic_r1.json"):
                 try:
                     tj = json.load(open(os.path.join(ROOT, "profiles", name)))
-                    if (m, n, d) == (50000, 50000, 0.01) and not args.exact and not (args.lds_cols or args.waves) \
+                    if (m, n, d) == (50000, 50000, 0.01) and not args.exact and not (args.lds_cols or args.waves or args.slab) \
                             and sorted(tj.get("kernels", ["smm_numeric"])) == ran:
                         traffic = tj["traffic_bytes_per_launch"]
                         traffic_src = f"profiles/{name} (static: PMC passes of this workload and these kernels, not measured in this run)"

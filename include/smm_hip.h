@@ -84,6 +84,11 @@ int  smm_ctx_tune_shared(smm_ctx *ctx, int lds_cols, int waves);      /* default
  * LDS hash table (one wave / one workgroup per row) instead of dense LDS tiles; 0, 0 turns the
  * hash kernels off.  Defaults 256 / 2048. */
 int  smm_ctx_tune_hash(smm_ctx *ctx, int small_max, int medium_max);
+/* Row-block x column-slab numeric kernels (B's gather served by the XCD's L2; values always in the
+ * reference's order).  mode 0 = used where they pay (default), 1 = never, 2 = wherever they can run;
+ * ws = slab width in columns (0 = sized so that one slab of B is L2-resident); rows_per_wave 2 or 4
+ * (0 keeps the setting).  Results do not depend on any of it beyond default-mode rounding. */
+int  smm_ctx_tune_slab(smm_ctx *ctx, int mode, int ws, int rows_per_wave);
 
 /* ------------------------------------------------------------------ operands
  * Replaces create_sparsemat + the three memmoves of csr_to_sparsemat

@@ -3,6 +3,7 @@
 // kernels of smm_kernels.hpp.  There is deliberately no CPU compute path in this file: with
 // no device every entry point fails with SMM_ERR_NO_DEVICE.
 #include "smm_kernels.hpp"
+#include "smm_slab.hpp"
 #include "../../include/smm_hip.h"
 
 #include <algorithm>
@@ -63,6 +64,10 @@ struct smm_ctx {
     int waves_shared = 16;
     int hash_small = 256;    // rows of C with <= hash_small nonzeros: one wave per row, LDS hash (0 = off)
     int hash_medium = 2048;  // ... <= hash_medium: one workgroup per row, LDS hash; above: dense LDS tiles
+    // row block x column slab kernels (smm_slab.hpp): mode 0 = where they pay, 1 = never, 2 = wherever
+    // they can run; ws = slab width (0 = sized so that one slab of B is ~3 MB, L2-resident);
+    // rows per wave 2 or 4 (8 waves per workgroup: 16 or 32 rows per block)
+    int slab_mode = 0, slab_ws = 0, slab_rw = 4;
     int n_cu = 256;
     std::vector<PoolBlock> pool;          // free blocks
     std::map<void *, size_t> live;        // blocks handed out
@@ -271,6 +276,19 @@ extern "C" int smm_ctx_tune_hash(smm_ctx *c, int small_max, int medium_max)
     c->hash_medium = std::max(medium_max, small_max);
     return SMM_OK;
 }
+extern "C" int smm_ctx_tune_slab(smm_ctx *c, int mode, int ws, int rows_per_wave)
+{
+    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CTX_LOCK(c);
+    if (mode < 0 || mode > 2) return fail(SMM_ERR_INVALID, "slab mode must be 0 (auto), 1 (off) or 2 (force)");
+    if (ws < 0 || ws > 32766) return fail(SMM_ERR_INVALID, "slab width must be in [0,32766]");
+    if (rows_per_wave != 0 && rows_per_wave != 2 && rows_per_wave != 4)
+        return fail(SMM_ERR_INVALID, "rows per wave must be 0 (keep), 2 or 4");
+    c->slab_mode = mode;
+    c->slab_ws = ws;
+    if (rows_per_wave) c->slab_rw = rows_per_wave;
+    return SMM_OK;
+}
 extern "C" int smm_ctx_tune_shared(smm_ctx *c, int lds_cols, int waves)
 {
     if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
@@ -300,8 +318,10 @@ struct smm_csr {
     // default, another tuning, the ELL chunks of the triple product) never invalidates it
     struct SegCache { int wf, n_ft; int *seg; };
     struct LocCache { int wc; short *loc; };          // tile-local columns for coarse width wc
+    struct SlabCache { int ws, n_slabs; int *soff; short *scol; double *sval; };   // slab-major copy (smm_slab.hpp)
     std::vector<SegCache> segs;
     std::vector<LocCache> locs;
+    std::vector<SlabCache> slabs;
     // sliced-ELL copy for triple-product stage 2 (chunk width ell_chunk)
     int ell_chunk = 0, ell_nchunks = 0; int *ell_len = nullptr; int64_t *ell_off = nullptr;
     short *ell_col = nullptr; double *ell_val = nullptr;
@@ -391,6 +411,7 @@ extern "C" void smm_csr_destroy(smm_csr *m)
     if (m->owned) { (void)hipFree((void *)m->ptr); (void)hipFree((void *)m->idx); (void)hipFree((void *)m->val); }
     for (auto &e : m->segs) (void)hipFree(e.seg);
     for (auto &e : m->locs) (void)hipFree(e.loc);
+    for (auto &e : m->slabs) { (void)hipFree(e.soff); (void)hipFree(e.scol); (void)hipFree(e.sval); }
     (void)hipFree(m->ell_len); (void)hipFree(m->ell_off); (void)hipFree(m->ell_col); (void)hipFree(m->ell_val);
     delete m;
 }
@@ -551,12 +572,12 @@ extern "C" int smm_row_products(smm_ctx *c, const smm_csr *a, const smm_csr *b, 
 }
 
 // ------------------------------------------------------------------------------ numeric dispatch
-template <int OUT, bool SYM, int NW, bool EXACT>
+template <int OUT, bool SYM, int NW, bool EXACT, bool SCR = false>
 static int launch_numeric_t(smm_ctx *c, NumericArgs &args)
 {
     // accumulator tile (+ the exact walk's per-wave scratch behind it)
     const size_t lds = (size_t)((args.wc + 1) & ~1) * sizeof(double) + (EXACT ? (size_t)NW * sizeof(ExactScratch) : 0);
-    auto kern = smm_numeric<OUT, SYM, NW, EXACT>;
+    auto kern = smm_numeric<OUT, SYM, NW, EXACT, SCR>;
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t grid = (int64_t)args.m * args.nct;
@@ -567,7 +588,7 @@ static int launch_numeric_t(smm_ctx *c, NumericArgs &args)
     (void)hipMemsetAsync(d_st, 0, 32, c->stream);
     args.stamps = d_st;
 #endif
-    LAUNCH(c, OUT == OUT_SPARSE ? "smm_numeric" : "smm_numeric_dense", kern, grid, NW * 64, lds, args);
+    LAUNCH(c, SCR ? "smm_emit" : OUT == OUT_SPARSE ? "smm_numeric" : "smm_numeric_dense", kern, grid, NW * 64, lds, args);
     hipError_t e = hipGetLastError();
 #ifdef SMM_STAMPS
     {
@@ -601,6 +622,8 @@ static int launch_numeric(smm_ctx *c, NumericArgs &args, bool sym, int nw, bool 
 }
 
 // ------------------------------------------------------------------------------ CSR x CSR -> CSR
+struct SlabGeom { int ws, n_slabs, rw; };
+constexpr int SLAB_NW = 8;                       // waves per workgroup of smm_dense_slab
 struct smm_plan {
     smm_ctx *ctx = nullptr;
     smm_csr *a = nullptr, *b = nullptr;
@@ -615,6 +638,9 @@ struct smm_plan {
     unsigned *d_runs = nullptr;    // nnz(A) x (nct+1)
     const int *seg = nullptr;      // B's tile index and tile-local columns for geometry g (owned by b)
     const short *loc = nullptr;
+    bool use_slab = false;         // dense-bin rows: smm_dense_slab -> scratch -> emission, instead of the tile kernel
+    SlabGeom sg{};
+    const smm_csr::SlabCache *slab = nullptr;
     int *d_rowcnt = nullptr;       // m
     int *d_lists = nullptr;        // 3 x m: rows of the small / medium / dense bins
     int n_bin[3] = {0, 0, 0};
@@ -653,6 +679,124 @@ static int scan_launch(smm_ctx *c, int64_t n, const T *in, int64_t *out)
     pool_free(c, sums);         // stream-ordered reuse: the pool hands it out again only to work queued behind these launches
     if (e != hipSuccess) return fail(SMM_ERR_HIP, "scan: %s", hipGetErrorString(e));
     return SMM_OK;
+}
+
+// ------------------------------------------------------------------------------ row block x column slab path
+
+// Slab width: the slab's share of B's payload (10 bytes per entry) should sit in one XCD's 4 MiB L2 next
+// to the streams that pass through it, and R rows of it must fit the LDS.  Returns false when the
+// slab kernels cannot run for this operand.
+static bool slab_geometry(const smm_ctx *c, const smm_csr *b, int64_t ncols, SlabGeom *g)
+{
+    if ((b->vflags & CSR_UNSORTED) || ncols <= 0 || b->nnz <= 0) return false;
+    const int rw = c->slab_rw;
+    const int R = SLAB_NW * rw;
+    const int64_t lds_doubles = ((int64_t)160 * 1024 - (int64_t)SLAB_NW * (int64_t)sizeof(SlabScratch)) / 8;
+    int64_t ws_lds = (lds_doubles / R) & ~(int64_t)1;
+    int64_t ws = c->slab_ws;
+    if (ws <= 0) {
+        const double l2_bytes = 3.0e6;
+        ws = (int64_t)(l2_bytes * (double)ncols / (10.0 * (double)b->nnz));
+        if (ws < 64) ws = 64;
+    }
+    ws = std::min<int64_t>(std::min<int64_t>(ws, ws_lds), std::min<int64_t>(ncols, 32766));
+    if (ws < 1) return false;
+    int64_t ns = (ncols + ws - 1) / ws;
+    if (ns >= 8 && c->slab_ws <= 0) ns = (ns + 7) & ~(int64_t)7;       // whole slabs per XCD
+    ws = (ncols + ns - 1) / ns;
+    ws = (ws + 1) & ~(int64_t)1;
+    if (ws > ws_lds) ws = ws_lds;
+    ns = (ncols + ws - 1) / ws;
+    if (ns * b->rows + 1 >= INT32_MAX) return false;
+    g->ws = (int)ws; g->n_slabs = (int)ns; g->rw = rw;
+    return true;
+}
+
+static int ensure_slab(smm_ctx *c, smm_csr *b, const SlabGeom &g, const smm_csr::SlabCache **out)
+{
+    for (auto &e : b->slabs)
+        if (e.ws == g.ws && e.n_slabs == g.n_slabs) { *out = &e; return SMM_OK; }
+    Geom gs; gs.nw = 1; gs.nct = g.n_slabs; gs.wc = g.ws; gs.wf = g.ws; gs.n_ft = g.n_slabs;
+    const int *seg = nullptr;
+    CHK(ensure_seg(c, b, gs, &seg));
+    const int64_t cells = (int64_t)g.n_slabs * b->rows;
+    int *cnt = nullptr; int64_t *off64 = nullptr;
+    CHK(pool_get(c, (size_t)std::max<int64_t>(cells, 1), &cnt));
+    int rc = pool_get(c, (size_t)cells + 1, &off64);
+    if (rc != SMM_OK) { pool_free(c, cnt); return rc; }
+    smm_csr::SlabCache e{g.ws, g.n_slabs, nullptr, nullptr, nullptr};
+    if (hipMalloc((void **)&e.soff, (size_t)(cells + 1) * sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&e.scol, (size_t)std::max<int64_t>(b->nnz, 1) * sizeof(short)) != hipSuccess ||
+        hipMalloc((void **)&e.sval, (size_t)std::max<int64_t>(b->nnz, 1) * sizeof(double)) != hipSuccess) {
+        (void)hipFree(e.soff); (void)hipFree(e.scol); (void)hipFree(e.sval);
+        pool_free(c, cnt); pool_free(c, off64);
+        return fail(SMM_ERR_ALLOC, "hipMalloc of the slab-major copy of B failed");
+    }
+    if (cells > 0) LAUNCH(c, "smm_slab_count", smm_slab_count, (cells + 255) / 256, 256, 0, (int)b->rows, g.n_slabs, seg, cnt);
+    rc = scan_launch<int>(c, cells, cnt, off64);
+    if (rc == SMM_OK) {
+        LAUNCH(c, "smm_narrow32", smm_narrow32, std::min<int64_t>((cells + 256) / 256, 65536), 256, 0, cells + 1, (const int64_t *)off64, e.soff);
+        if (b->rows > 0)
+            LAUNCH(c, "smm_slab_fill", smm_slab_fill, std::min<int64_t>((b->rows + 3) / 4, 65536), 256, 0, (int)b->rows, g.n_slabs, g.ws,
+                   b->ptr, b->idx, b->val, seg, (const int *)e.soff, e.scol, e.sval);
+        hipError_t he = hipGetLastError();
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);        // cnt / off64 go back to the pool
+        if (he != hipSuccess) rc = fail(SMM_ERR_HIP, "slab build: %s", hipGetErrorString(he));
+    }
+    pool_free(c, cnt); pool_free(c, off64);
+    if (rc != SMM_OK) { (void)hipFree(e.soff); (void)hipFree(e.scol); (void)hipFree(e.sval); return rc; }
+    b->slabs.push_back(e);
+    *out = &b->slabs.back();
+    return SMM_OK;
+}
+
+// rows (a row list, or rows 0..m-1 of A) x all slabs -> `out`, rows of the launch ldo apart, column order
+template <bool NEGZERO>
+static int launch_slab(smm_ctx *c, const smm_csr *a, const smm_csr *b, const smm_csr::SlabCache &sl, int rw, int m,
+                       const int *rowlist, bool sym, int64_t row_offset, double *out, int64_t ldo)
+{
+    if (m <= 0) return SMM_OK;
+    SlabArgs S{};
+    const int R = SLAB_NW * rw;
+    S.m = m; S.ncols = (int)b->cols; S.ws = sl.ws; S.n_slabs = sl.n_slabs; S.n_rb = (m + R - 1) / R; S.rowsB = (int)b->rows;
+    S.row_offset = row_offset; S.rowlist = rowlist;
+    S.a_ptr = a->ptr; S.a_idx = a->idx; S.a_val = a->val;
+    S.soff = sl.soff; S.scol = sl.scol; S.sval = sl.sval;
+    S.dummy_idx = (const int *)((const char *)c->d_flags + 64);
+    S.dummy_val = (const double *)((const char *)c->d_flags + 128);
+    S.out = out; S.ldo = ldo;
+    const int64_t units = (int64_t)S.n_rb * S.n_slabs;
+    S.cpx = (int)((units + 7) / 8);
+    const int64_t grid = (int64_t)S.cpx * 8;
+    if (grid > 0x7fffffff) return fail(SMM_ERR_INVALID, "too many (row block, slab) units for one launch");
+    const size_t lds = (size_t)R * ((sl.ws + 1) & ~1) * sizeof(double) + (size_t)SLAB_NW * sizeof(SlabScratch);
+#define SLAB_CASE(S_, RW_)                                                                                       \
+    if (sym == S_ && rw == RW_) {                                                                                \
+        auto kern = smm_dense_slab<S_, SLAB_NW, RW_, NEGZERO>;                                                   \
+        if (lds > 64 * 1024)                                                                                     \
+            HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        LAUNCH(c, "smm_dense_slab", kern, grid, SLAB_NW * 64, lds, S);                                           \
+        LAUNCH_CHECK();                                                                                          \
+        return SMM_OK;                                                                                           \
+    }
+    SLAB_CASE(false, 2) SLAB_CASE(true, 2) SLAB_CASE(false, 4) SLAB_CASE(true, 4)
+#undef SLAB_CASE
+    return fail(SMM_ERR_INVALID, "unsupported slab configuration");
+}
+
+// Does the slab path pay?  It moves A's metadata once per slab and, for CSR output, the dense scratch
+// twice; the tile kernel moves 10 bytes per product through the fabric.  `cells` = rows x columns of the
+// launch, `products` their multiply-adds (an estimate is enough), `nnz_c` < 0 for dense output.
+static bool slab_pays(const smm_ctx *c, const smm_csr *a, const SlabGeom &g, double cells, double products, double nnz_c)
+{
+    if (c->slab_mode == 1) return false;
+    if (c->slab_mode == 2) return true;
+    if (cells <= 0) return false;
+    const double tile_bytes = 10.0 * products;
+    double slab_bytes = 12.0 * (double)a->nnz * g.n_slabs + 8.0 * (double)a->nnz * g.n_slabs   /* A and soff per slab */
+                        + 2.5 * products;                                                          /* ~3/4 of the gather hits L2 */
+    if (nnz_c >= 0) slab_bytes += 16.0 * cells;                                                    /* scratch out and back */
+    return slab_bytes < 0.7 * tile_bytes && products > 1e7;
 }
 
 template <bool SYM, bool SAFE, int MARK, int UNROLL = 16>
@@ -811,8 +955,15 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "row binning: %s", hipGetErrorString(e)); }
     }
     if (p->b_sorted && p->n_bin[2] > 0) {
-        PCHK(ensure_seg(c, b, p->g, &p->seg));
-        PCHK(ensure_loc(c, b, p->g, &p->loc));
+        const double est_products = (double)a->nnz * ((double)b->nnz / (double)std::max<int64_t>(b->rows, 1)) *
+                                    ((double)p->n_bin[2] / (double)m);
+        p->use_slab = slab_geometry(c, b, p->ncols, &p->sg) &&
+                      slab_pays(c, a, p->sg, (double)p->n_bin[2] * (double)p->ncols, est_products, (double)p->nnz);
+        if (p->use_slab) PCHK(ensure_slab(c, b, p->sg, &p->slab));
+        else {
+            PCHK(ensure_seg(c, b, p->g, &p->seg));
+            PCHK(ensure_loc(c, b, p->g, &p->loc));
+        }
         PCHK(pool_get(c, (size_t)a->nnz * (p->g.nct + 1), &p->d_runs));
         const int nd = p->n_bin[2];
         const int rgrid = (int)std::min<int64_t>((nd + 3) / 4, 65536);
@@ -880,6 +1031,20 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
         A.b_idx = p->b->idx; A.b_val = p->b->val; A.seg = p->seg; A.b_loc = p->loc;
         A.c_ptr = p->d_cptr; A.c_idx = d_c_indices; A.c_val = d_c_data;
         A.ub_off = p->d_ub_off; A.tmp_idx = p->d_tmp; A.runs = p->d_runs;
+        if (p->use_slab) {
+            // values in column order into a dense scratch (one row per row of the bin), then the emission
+            double *scratch = nullptr;
+            CHK(pool_get(c, (size_t)nd * (size_t)p->ncols, &scratch));
+            int rc = launch_slab<true>(c, p->a, p->b, *p->slab, p->sg.rw, nd, dense_rows, sym, p->row_offset, scratch, p->ncols);
+            if (rc == SMM_OK) {
+                A.c_dense = scratch; A.ldc = p->ncols;
+                A.dummy_idx = (const int *)((const char *)c->d_flags + 64);
+                A.dummy_val = (const double *)((const char *)c->d_flags + 128);
+                rc = sym ? launch_numeric_t<OUT_SPARSE, true, 16, false, true>(c, A) : launch_numeric_t<OUT_SPARSE, false, 16, false, true>(c, A);
+            }
+            pool_free(c, scratch);          // stream-ordered: only work queued behind the emission can get it
+            return rc;
+        }
         CHK(launch_numeric<OUT_SPARSE>(c, A, sym, p->g.nw, exact));
     } else {
         const int cgrid = (int)std::min<int64_t>(nd, 65536);
@@ -951,6 +1116,13 @@ static int dense_into(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t row
     if (a->nnz == 0 || b->nnz == 0) {
         HIPCHK(hipMemset2DAsync(d_c, ldc * sizeof(double), 0, n * sizeof(double), m, c->stream));
         return SMM_OK;
+    }
+    SlabGeom sg;
+    if (slab_geometry(c, b, n, &sg) &&
+        slab_pays(c, a, sg, (double)m * (double)n, (double)a->nnz * ((double)b->nnz / (double)std::max<int64_t>(b->rows, 1)), -1.0)) {
+        const smm_csr::SlabCache *sl = nullptr;
+        CHK(ensure_slab(c, b, sg, &sl));
+        return launch_slab<false>(c, a, b, *sl, sg.rw, (int)m, nullptr, sym, row_offset, d_c, ldc);
     }
     if (!(b->vflags & CSR_UNSORTED)) {
         Geom g = make_geom(c, n, b, (flags & SMM_EXACT) != 0);
@@ -1034,7 +1206,7 @@ extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags,
     CHK(pool_get(c, (size_t)nr * K, &T));
     if (q->cols < K) HIPCHK(hipMemsetAsync(T, 0, (size_t)nr * K * sizeof(double), c->stream));
     smm_csr hv = *h;                       // row-range view of H (borrowed arrays)
-    hv.ptr = h->ptr + row_begin; hv.rows = nr; hv.owned = false; hv.segs.clear(); hv.locs.clear();
+    hv.ptr = h->ptr + row_begin; hv.rows = nr; hv.owned = false; hv.segs.clear(); hv.locs.clear(); hv.slabs.clear();
     // indptr of the view is not rebased: kernels only use ptr[row], ptr[row+1] as absolute positions.
     int rc = dense_into(c, &hv, q, flags & SMM_EXACT, 0, T, K);
     if (rc != SMM_OK) { pool_free(c, T); return rc; }

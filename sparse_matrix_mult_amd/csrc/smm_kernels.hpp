@@ -818,9 +818,13 @@ __device__ __forceinline__ void smm_accumulate_shared(const NumericArgs &A, doub
 #endif
 constexpr int EPI_UNROLL = SMM_EPI_UNROLL;
 
-template <int OUT, bool SYM, int NW, bool EXACT>
+// SCR: the tile is not accumulated here but loaded from the dense scratch rows smm_dense_slab left
+// in column order (A.c_dense / A.ldc, one scratch row per row of the launch); the kernel is then only
+// the first-touch emission.
+template <int OUT, bool SYM, int NW, bool EXACT, bool SCR = false>
 __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
 {
+    static_assert(!SCR || OUT == OUT_SPARSE, "the scratch source feeds the CSR emission only");
     extern __shared__ double acc[];
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -857,12 +861,18 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
     if (SYM) { const int64_t d = gi - lo_c; thresh = d < 0 ? 0 : (d > 32767 ? 32767 : (int)d); }
 
     SMM_MARK();
-    for (int x = threadIdx.x; x < A.wc; x += NT) acc[x] = zero;
-    if (NW > 1) __syncthreads();
-    SMM_LAP(t_init);
-    if (!below && a1 > a0) {
-        if (EXACT) smm_accumulate<SYM>(A, acc, (ExactScratch *)(acc + ((A.wc + 1) & ~1)) + wave, thresh, a0, a1, tc * NW + wave);
-        else       smm_accumulate_shared<SYM, NW>(A, acc, lo_c, thresh, a0, a1, tc, wave);
+    if (SCR) {
+        const double *__restrict__ src = A.c_dense + (int64_t)ridx * A.ldc + lo_c;
+        for (int x = threadIdx.x; x < w; x += NT) acc[x] = src[x];
+        SMM_LAP(t_init);
+    } else {
+        for (int x = threadIdx.x; x < A.wc; x += NT) acc[x] = zero;
+        if (NW > 1) __syncthreads();
+        SMM_LAP(t_init);
+        if (!below && a1 > a0) {
+            if (EXACT) smm_accumulate<SYM>(A, acc, (ExactScratch *)(acc + ((A.wc + 1) & ~1)) + wave, thresh, a0, a1, tc * NW + wave);
+            else       smm_accumulate_shared<SYM, NW>(A, acc, lo_c, thresh, a0, a1, tc, wave);
+        }
     }
     if (NW > 1) __syncthreads();
     SMM_LAP(t_acc);

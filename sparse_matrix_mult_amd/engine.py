@@ -71,6 +71,11 @@ class Context:
         (0, 0 = dense LDS tiles for every row)."""
         check(self.lib, self.lib.smm_ctx_tune_hash(self.handle, int(small_max), int(medium_max)))
 
+    def tune_slab(self, mode=0, ws=0, rows_per_wave=0):
+        """Row-block x column-slab kernels: mode 0 auto / 1 off / 2 force; ws = slab width (0 = L2-sized);
+        rows_per_wave 2 or 4."""
+        check(self.lib, self.lib.smm_ctx_tune_slab(self.handle, int(mode), int(ws), int(rows_per_wave)))
+
     def timing(self, enable=True):
         check(self.lib, self.lib.smm_ctx_timing(self.handle, 1 if enable else 0))
 
