@@ -691,7 +691,7 @@ static bool slab_geometry(const smm_ctx *c, const smm_csr *b, int64_t ncols, Sla
     if ((b->vflags & CSR_UNSORTED) || ncols <= 0 || b->nnz <= 0) return false;
     const int rw = c->slab_rw;
     const int R = SLAB_NW * rw;
-    const int64_t lds_doubles = ((int64_t)160 * 1024 - (int64_t)SLAB_NW * (int64_t)sizeof(SlabScratch)) / 8;
+    const int64_t lds_doubles = ((int64_t)160 * 1024 - (int64_t)SLAB_NW * (int64_t)sizeof(SlabScratch) - (int64_t)sizeof(SlabShared)) / 8;
     int64_t ws_lds = (lds_doubles / R) & ~(int64_t)1;
     int64_t ws = c->slab_ws;
     if (ws <= 0) {
@@ -760,6 +760,7 @@ static int launch_slab(smm_ctx *c, const smm_csr *a, const smm_csr *b, const smm
     const int R = SLAB_NW * rw;
     S.m = m; S.ncols = (int)b->cols; S.ws = sl.ws; S.n_slabs = sl.n_slabs; S.n_rb = (m + R - 1) / R; S.rowsB = (int)b->rows;
     S.row_offset = row_offset; S.rowlist = rowlist;
+    S.kmax = (int)std::max<int64_t>(b->nnz - 1, 0);
     S.a_ptr = a->ptr; S.a_idx = a->idx; S.a_val = a->val;
     S.soff = sl.soff; S.scol = sl.scol; S.sval = sl.sval;
     S.dummy_idx = (const int *)((const char *)c->d_flags + 64);
@@ -769,7 +770,7 @@ static int launch_slab(smm_ctx *c, const smm_csr *a, const smm_csr *b, const smm
     S.cpx = (int)((units + 7) / 8);
     const int64_t grid = (int64_t)S.cpx * 8;
     if (grid > 0x7fffffff) return fail(SMM_ERR_INVALID, "too many (row block, slab) units for one launch");
-    const size_t lds = (size_t)R * ((sl.ws + 1) & ~1) * sizeof(double) + (size_t)SLAB_NW * sizeof(SlabScratch);
+    const size_t lds = (size_t)R * ((sl.ws + 1) & ~1) * sizeof(double) + (size_t)SLAB_NW * sizeof(SlabScratch) + sizeof(SlabShared);
 #define SLAB_CASE(S_, RW_)                                                                                       \
     if (sym == S_ && rw == RW_) {                                                                                \
         auto kern = smm_dense_slab<S_, SLAB_NW, RW_, NEGZERO>;                                                   \

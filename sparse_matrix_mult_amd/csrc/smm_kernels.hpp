@@ -69,6 +69,49 @@ __device__ __forceinline__ void load_masked(int &v, const int *idx, unsigned lon
                  : "+v"(v)
                  : "v"(lane4), "s"(idx), "s"(mask));
 }
+// Inclusive prefix sum over the 64 lanes with DPP (no LDS traffic; __shfl_up is a ds_bpermute -- one LDS
+// round trip per step): shifts by 1, 2, 4, 8 inside the rows of 16 lanes, then the last lane of row 0 / 2
+// into row 1 / 3 (row_bcast:15) and lane 31 into rows 2 and 3 (row_bcast:31) -- gfx9 wave64 forms.
+__device__ __forceinline__ int wave_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+// Hand-issued memory operations for loops whose order of issue matters more than the compiler's view of
+// them (it sinks loads into the branch of their first use, or turns selects back into branches).  The
+// compiler does not know these are in flight: a value loaded by gload_* may be read only behind
+// wait_vm_pair(), and asm ds_add's are drained with wait_lgkm0() before a barrier.  Its own s_waitcnt's
+// stay correct -- counters retire in order, and it can only under-estimate what is outstanding.
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char *)p;
+}
+__device__ __forceinline__ void gload_sshort(int &dst, const short *p) {
+    asm volatile("global_load_sshort %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void gload_f64(double &dst, const double *p) {
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void gload_touch(int &dst, const void *p) {
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void lds_add_asm(unsigned addr, double x) {
+    asm volatile("ds_add_f64 %0, %1" ::"v"(addr), "v"(x) : "memory");
+}
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wait_vm_pair(int &c, double &v, int n) {
+#define SMM_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(c), "+v"(v) : : "memory"); break;
+    switch (n) {
+        SMM_W(0) SMM_W(1) SMM_W(2) SMM_W(3) SMM_W(4) SMM_W(5) SMM_W(6) SMM_W(7)
+        SMM_W(8) SMM_W(9) SMM_W(10) SMM_W(11) SMM_W(12) SMM_W(13) SMM_W(14) SMM_W(15)
+        SMM_W(16) SMM_W(17) SMM_W(18) SMM_W(19) SMM_W(20) SMM_W(21) SMM_W(22) SMM_W(23)
+        SMM_W(24) SMM_W(25) SMM_W(26) SMM_W(27) SMM_W(28) SMM_W(29) SMM_W(30) SMM_W(31)
+    }
+#undef SMM_W
+}
 // n is a constant after unrolling; the switch folds to one s_waitcnt
 __device__ __forceinline__ void wait_vm(int &v, int n) {
 #define SMM_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(v)); break;

@@ -74,6 +74,7 @@ struct SlabArgs {
     int m;                          // rows handled by this launch (length of rowlist, or rows of A)
     int ncols, ws, n_slabs, n_rb, rowsB;
     int cpx;                        // units per XCD = ceil(n_rb*n_slabs / 8)
+    int kmax;                       // last valid position of scol / sval (lanes past a stream's end read it)
     int64_t row_offset;
     const int *rowlist;             // NULL = rows 0..m-1
     const int *a_ptr, *a_idx; const double *a_val;
@@ -89,6 +90,7 @@ struct SlabScratch {                // per wave, in LDS behind the accumulators
     unsigned char head[WAVE * SLAB_UNROLL];   // one round of the stream: entry index + 1 where a segment starts
     int4 rows[4];                   // the wave's rows
 };
+struct SlabShared { double sink[WAVE]; };   // per workgroup: lanes with nothing to add put -0.0 here (branch-free adds)
 
 // Block index -> unit -> (slab, row block).  Units are numbered slab-major (u = slab*n_rb + row block).
 // Workgroups are dealt round-robin over the 8 XCDs (observed, speed only: blocks b and b+8 share an
@@ -111,8 +113,8 @@ __global__ __launch_bounds__(NW * 64) void smm_dense_slab(const SlabArgs A)
     const int w = (A.ncols - lo_c) < A.ws ? (A.ncols - lo_c) : A.ws;
     const int wsp = (A.ws + 1) & ~1;
     const double zero = NEGZERO ? -0.0 : 0.0;
-    for (int x = threadIdx.x; x < R * wsp; x += NT) acc[x] = zero;
     SlabScratch *sc = (SlabScratch *)(acc + (size_t)R * wsp) + wave;
+    double *sink = ((SlabShared *)((SlabScratch *)(acc + (size_t)R * wsp) + NW))->sink;
 
     // this wave's rows: numbers rb*R + wave*RW + i of the launch; their entries of A form one stream.
     // Row i's (first entry of A, first stream position, column threshold) sit in a 4-entry LDS table of the
@@ -136,14 +138,31 @@ __global__ __launch_bounds__(NW * 64) void smm_dense_slab(const SlabArgs A)
         sc->rows[i] = make_int4(s, incl - (e - s), th, incl);
     }
     wave_sync();
+    // Touch every line of this wave's rows of A now: they come through the fabric (A is streamed once per
+    // slab), and the walk below must wait for whatever it requested BEFORE its chunk loads (vmcnt retires in
+    // order).  Requested here, their latency passes while the tile is cleared, and the walk's own loads of A
+    // are L2 hits like everything else it touches.
+    int warm = 0;
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int4 ri = sc->rows[i];
+        const int cnt = ri.w - ri.y;
+        const char *pi = (const char *)(A.a_idx + ri.x), *pv = (const char *)(A.a_val + ri.x);
+        for (int o = lane * 128; o < cnt * 4; o += WAVE * 128) gload_touch(warm, pi + o);
+        for (int o = lane * 128; o < cnt * 8; o += WAVE * 128) gload_touch(warm, pv + o);
+        if (cnt > 0 && lane == 63) { gload_touch(warm, pi + cnt * 4 - 4); gload_touch(warm, pv + cnt * 8 - 8); }
+    }
+    for (int x = threadIdx.x; x < R * wsp; x += NT) acc[x] = zero;
+    if (threadIdx.x < WAVE) sink[threadIdx.x] = -0.0;
     const int E = sc->rows[3].w;
     __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(warm) : : "memory");      // the touches have landed (their register is free again)
+    const unsigned acc_a = lds_addr(acc), sink_a = lds_addr(sink) + 8u * (unsigned)lane;
 
     if (E > 0) {
         const int *__restrict__ soff = A.soff + (size_t)t * A.rowsB;
         const short *__restrict__ bi = A.scol;
         const double *__restrict__ bv = A.sval;
-        const short *__restrict__ dummy_c = (const short *)A.dummy_idx;
         const unsigned long long le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);   // lanes <= this one
 
         // entry number x of the stream: which row (i), which entry of A
@@ -178,19 +197,14 @@ __global__ __launch_bounds__(NW * 64) void smm_dense_slab(const SlabArgs A)
             load_a(xb + 2 * WAVE, r_nn, a_nn, pk_nn);      // entries of A two batches ahead
             // stream of this batch: entry j owns positions [first_j, first_j + len_j)
             const int len = lane < nb ? e_c - s_c : 0;
-            int incl = len;
-#pragma unroll
-            for (int o = 1; o < WAVE; o <<= 1) {
-                const int y = __shfl_up(incl, o);
-                if (lane >= o) incl += y;
-            }
+            const int incl = wave_scan_incl(len);
             const int first = incl - len;
             const int total = rl(incl, WAVE - 1);
             wave_sync();
             sc->tab[lane] = make_int4(s_c - first, pk_c, __double2loint(a_c), __double2hiint(a_c));
             wave_sync();
             for (int g0 = 0; g0 < total; g0 += WAVE * SLAB_UNROLL) {
-                int c[SLAB_UNROLL], pk[SLAB_UNROLL];
+                int c[SLAB_UNROLL], pk[SLAB_UNROLL], kk[SLAB_UNROLL];
                 double v[SLAB_UNROLL], a[SLAB_UNROLL];
                 // heads of this round: entries whose segment starts inside it
                 wave_sync();
@@ -199,9 +213,8 @@ __global__ __launch_bounds__(NW * 64) void smm_dense_slab(const SlabArgs A)
                 if (len > 0 && first >= g0 && first < g0 + WAVE * SLAB_UNROLL) sc->head[first - g0] = (unsigned char)(lane + 1);
                 wave_sync();
 #pragma unroll
-                for (int u = 0; u < SLAB_UNROLL; ++u) {     // map + load the chunks of the round ...
+                for (int u = 0; u < SLAB_UNROLL; ++u) {     // owner of every stream position of the round
                     const int gbase = g0 + u * WAVE;        // wave-uniform
-                    const int g = gbase + lane;
                     const int hd = sc->head[u * WAVE + lane];
                     const unsigned long long heads = __ballot(hd != 0);
                     // entry that owns the chunk's first position when no head precedes a lane
@@ -212,23 +225,34 @@ __global__ __launch_bounds__(NW * 64) void smm_dense_slab(const SlabArgs A)
                     if (mine == 0ull) j = carry;
                     j = j < WAVE ? j : WAVE - 1;
                     const int4 tb = sc->tab[j];
-                    const bool p = g < total;
-                    const int k = tb.x + g;
-                    const short *ip = p ? bi + k : dummy_c;
-                    const double *vp = p ? bv + k : A.dummy_val;
-                    c[u] = *ip;
-                    v[u] = *vp;
+                    const int k = tb.x + gbase + lane;      // positions past the end read the payload's last entry
+                    kk[u] = k < A.kmax ? k : A.kmax;
                     pk[u] = tb.y;
                     a[u] = __hiloint2double(tb.w, tb.z);
                 }
 #pragma unroll
-                for (int u = 0; u < SLAB_UNROLL; ++u)       // ... then add, lane order = stream order
-                    if (c[u] >= (pk[u] & 0xffff)) lds_add(&acc[(pk[u] >> 16) * wsp + c[u]], a[u] * v[u]);
+                for (int u = 0; u < SLAB_UNROLL; ++u) {     // all loads of the round, back to back ...
+                    gload_sshort(c[u], bi + kk[u]);
+                    gload_f64(v[u], bv + kk[u]);
+                }
+                // ... then add, lane order = stream order.  Branch-free: a lane with nothing to add (past the
+                // end of the stream, or left of the diagonal) adds -0.0 -- neutral for every accumulator value --
+                // into its slot of the sink.  (With `if (keep) add` the compiler sank the value load of the
+                // round's first chunk into the branch: a second, dependent round trip per round.)
+#pragma unroll
+                for (int u = 0; u < SLAB_UNROLL; ++u) {
+                    wait_vm_pair(c[u], v[u], 2 * (SLAB_UNROLL - 1 - u));
+                    const bool keep = (g0 + u * WAVE + lane) < total && c[u] >= (pk[u] & 0xffff);
+                    const double prod = a[u] * v[u];
+                    const unsigned at = acc_a + 8u * (unsigned)((pk[u] >> 16) * wsp + c[u]);
+                    lds_add_asm(keep ? at : sink_a, keep ? prod : -0.0);
+                }
             }
             s_c = s_n; e_c = e_n; a_c = a_n; pk_c = pk_n;
             r_n = r_nn; a_n = a_nn; pk_n = pk_nn;
         }
     }
+    wait_lgkm0();                                           // the hand-issued ds_add's (the compiler does not count them)
     __syncthreads();
 
     // the block's R x w tile, in column order (each wave writes whole rows: 512 contiguous bytes per instruction)
