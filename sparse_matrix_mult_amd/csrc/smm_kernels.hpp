@@ -83,8 +83,8 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
 }
 // Hand-issued memory operations for loops whose order of issue matters more than the compiler's view of
 // them (it sinks loads into the branch of their first use, or turns selects back into branches).  The
-// compiler does not know these are in flight: a value loaded by gload_* may be read only behind
-// wait_vm_pair(), and asm ds_add's are drained with wait_lgkm0() before a barrier.  Its own s_waitcnt's
+// compiler does not know these are in flight: a value loaded by gload_* must be defined ONCE and read only behind
+// wait_vm_pair() (a re-defined destination frees its register while the first load is still in flight), and asm ds_add's are drained with wait_lgkm0() before a barrier.  Its own s_waitcnt's
 // stay correct -- counters retire in order, and it can only under-estimate what is outstanding.
 __device__ __forceinline__ unsigned lds_addr(const void *p) {
     return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char *)p;
@@ -94,9 +94,6 @@ __device__ __forceinline__ void gload_sshort(int &dst, const short *p) {
 }
 __device__ __forceinline__ void gload_f64(double &dst, const double *p) {
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void gload_touch(int &dst, const void *p) {
-    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
 __device__ __forceinline__ void lds_add_asm(unsigned addr, double x) {
     asm volatile("ds_add_f64 %0, %1" ::"v"(addr), "v"(x) : "memory");

@@ -142,21 +142,26 @@ __global__ __launch_bounds__(NW * 64) void smm_dense_slab(const SlabArgs A)
     // slab), and the walk below must wait for whatever it requested BEFORE its chunk loads (vmcnt retires in
     // order).  Requested here, their latency passes while the tile is cleared, and the walk's own loads of A
     // are L2 hits like everything else it touches.
+    // (Plain loads, clamped instead of predicated, folded into one value that is "used" behind the barrier:
+    // the compiler issues them back to back and waits once.  The first 2048 entries of a row are touched;
+    // a longer row's tail simply is not pre-fetched.)
     int warm = 0;
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
         const int4 ri = sc->rows[i];
         const int cnt = ri.w - ri.y;
         const char *pi = (const char *)(A.a_idx + ri.x), *pv = (const char *)(A.a_val + ri.x);
-        for (int o = lane * 128; o < cnt * 4; o += WAVE * 128) gload_touch(warm, pi + o);
-        for (int o = lane * 128; o < cnt * 8; o += WAVE * 128) gload_touch(warm, pv + o);
-        if (cnt > 0 && lane == 63) { gload_touch(warm, pi + cnt * 4 - 4); gload_touch(warm, pv + cnt * 8 - 8); }
+        const int o = lane * 128;
+        auto clampo = [](int off, int last) { off = off < last ? off : last; return off > 0 ? off : 0; };
+        warm ^= *(const int *)(pi + clampo(o, cnt * 4 - 4));
+        warm ^= *(const int *)(pv + clampo(o, cnt * 8 - 8));
+        warm ^= *(const int *)(pv + clampo(o + WAVE * 128, cnt * 8 - 8));
     }
     for (int x = threadIdx.x; x < R * wsp; x += NT) acc[x] = zero;
     if (threadIdx.x < WAVE) sink[threadIdx.x] = -0.0;
     const int E = sc->rows[3].w;
     __syncthreads();
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(warm) : : "memory");      // the touches have landed (their register is free again)
+    asm volatile("" ::"v"(warm));                           // the touches are "used" here: one wait, behind the clear
     const unsigned acc_a = lds_addr(acc), sink_a = lds_addr(sink) + 8u * (unsigned)lane;
 
     if (E > 0) {
