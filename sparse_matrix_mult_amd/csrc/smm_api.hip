@@ -788,11 +788,18 @@ static int launch_slab(smm_ctx *c, const smm_csr *a, const smm_csr *b, const smm
 // Does the slab path pay?  It moves A's metadata once per slab and, for CSR output, the dense scratch
 // twice; the tile kernel moves 10 bytes per product through the fabric.  `cells` = rows x columns of the
 // launch, `products` their multiply-adds (an estimate is enough), `nnz_c` < 0 for dense output.
-static bool slab_pays(const smm_ctx *c, const smm_csr *a, const SlabGeom &g, double cells, double products, double nnz_c)
+static bool slab_pays(const smm_ctx *c, const smm_csr *a, const SlabGeom &g, double cells, double products, double nnz_c,
+                      double b_nnz_per_row, double ncols)
 {
     if (c->slab_mode == 1) return false;
     if (c->slab_mode == 2) return true;
     if (cells <= 0) return false;
+    // Measured (profiles/r2_c_slab_sweep.txt): with pieces of B's rows of 6-13 entries (50k x 50k, d = 0.01,
+    // slabs of 570-1100 columns) the kernel is bound by the L1's line look-ups -- every piece is its own
+    // 128-byte line, ~26 look-ups per 64-lane chunk against ~5 for the tile kernel -- and loses 1.4-1.8x.
+    // It is therefore chosen only where a slab-sized piece of a row of B is long.
+    const double piece = (double)b_nnz_per_row * g.ws / std::max<double>(1.0, ncols);
+    if (piece < 24.0) return false;
     const double tile_bytes = 10.0 * products;
     double slab_bytes = 12.0 * (double)a->nnz * g.n_slabs + 8.0 * (double)a->nnz * g.n_slabs   /* A and soff per slab */
                         + 2.5 * products;                                                          /* ~3/4 of the gather hits L2 */
@@ -959,7 +966,8 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         const double est_products = (double)a->nnz * ((double)b->nnz / (double)std::max<int64_t>(b->rows, 1)) *
                                     ((double)p->n_bin[2] / (double)m);
         p->use_slab = slab_geometry(c, b, p->ncols, &p->sg) &&
-                      slab_pays(c, a, p->sg, (double)p->n_bin[2] * (double)p->ncols, est_products, (double)p->nnz);
+                      slab_pays(c, a, p->sg, (double)p->n_bin[2] * (double)p->ncols, est_products, (double)p->nnz,
+                                (double)b->nnz / (double)std::max<int64_t>(b->rows, 1), (double)p->ncols);
         if (p->use_slab) PCHK(ensure_slab(c, b, p->sg, &p->slab));
         else {
             PCHK(ensure_seg(c, b, p->g, &p->seg));
@@ -1120,7 +1128,8 @@ static int dense_into(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t row
     }
     SlabGeom sg;
     if (slab_geometry(c, b, n, &sg) &&
-        slab_pays(c, a, sg, (double)m * (double)n, (double)a->nnz * ((double)b->nnz / (double)std::max<int64_t>(b->rows, 1)), -1.0)) {
+        slab_pays(c, a, sg, (double)m * (double)n, (double)a->nnz * ((double)b->nnz / (double)std::max<int64_t>(b->rows, 1)), -1.0,
+                  (double)b->nnz / (double)std::max<int64_t>(b->rows, 1), (double)n)) {
         const smm_csr::SlabCache *sl = nullptr;
         CHK(ensure_slab(c, b, sg, &sl));
         return launch_slab<false>(c, a, b, *sl, sg.rw, (int)m, nullptr, sym, row_offset, d_c, ldc);

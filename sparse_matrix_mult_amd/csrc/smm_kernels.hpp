@@ -856,6 +856,25 @@ __device__ __forceinline__ void smm_accumulate_shared(const NumericArgs &A, doub
 #ifndef SMM_EPI_UNROLL
 #define SMM_EPI_UNROLL 16
 #endif
+// Streams that are touched once (the result, the ordered lists) carry the non-temporal hint so that they
+// do not push B -- re-read by every row -- out of the Infinity Cache.  -DSMM_NT=0 builds without it.
+#ifndef SMM_NT
+#define SMM_NT 1
+#endif
+template <typename T> __device__ __forceinline__ void st_stream(T *p, T v) {
+#if SMM_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+template <typename T> __device__ __forceinline__ T ld_stream(const T *p) {
+#if SMM_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
 constexpr int EPI_UNROLL = SMM_EPI_UNROLL;
 
 // SCR: the tile is not accumulated here but loaded from the dense scratch rows smm_dense_slab left
@@ -919,7 +938,7 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
 
     if (OUT == OUT_DENSE) {
         double *__restrict__ dst = A.c_dense + (int64_t)row * A.ldc + lo_c;
-        for (int x = threadIdx.x; x < w; x += NT) dst[x] = acc[x];
+        for (int x = threadIdx.x; x < w; x += NT) st_stream(&dst[x], acc[x]);
     } else {
         // Epilogue.  Step e of the row put its new columns of this tile into the contiguous slots
         // [runs[e][tc], runs[e][tc+1]).  The sub-runs are cut into 64-lane chunks; wave w takes the
@@ -959,11 +978,11 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
                     sl[u] = s0 + ((unsigned)(t - first) << 6) + (unsigned)lane;
                     const bool p = t < total && sl[u] < s1;
                     const int *ip = p ? list + sl[u] : A.dummy_idx;
-                    c[u] = *ip;
+                    c[u] = ld_stream(ip);
                 }
 #pragma unroll
                 for (int u = 0; u < EPI_UNROLL; ++u)
-                    if (c[u] >= 0) { oi[sl[u]] = c[u]; ov[sl[u]] = acc[c[u] - lo_c]; }
+                    if (c[u] >= 0) { st_stream(&oi[sl[u]], c[u]); st_stream(&ov[sl[u]], acc[c[u] - lo_c]); }
             }
         }
     }
