@@ -39,6 +39,11 @@ enum smm_status {
 enum smm_flags {
     SMM_SYMMETRIC   = 1,  /* keep only i <= col   (sparsework.cpp:217, sparse_sparse_dense.cpp:59) */
     SMM_FULL_MATRIX = 2,  /* triple_product compute_full_matrix=1 (sparse_sparse_dense.cpp:201,213) */
+    SMM_MIRROR      = 8,  /* mirror epilogue (not in the reference): after an upper-triangle result -- dense with
+                             SMM_SYMMETRIC, or the triple product without SMM_FULL_MATRIX -- the lower triangle
+                             is filled with the mirror image of the upper one, i.e. the full symmetric matrix
+                             (what compute_full_matrix=1 was meant to give; SMM_FULL_MATRIX reproduces its
+                             doubling bug instead).  Whole square results only.                          */
     SMM_EXACT       = 4   /* add every product in exactly the reference's order: float64 values
                              are then bit-identical to the CPU loop (for operands with sorted
                              rows).  Without it the numeric phase lets the waves of a workgroup
@@ -130,6 +135,11 @@ int  smm_spgemm_numeric(smm_ctx *ctx, smm_plan *plan,
 /* Same, results copied into host buffers (numpy arrays owned by the caller). */
 int  smm_spgemm_numeric_host(smm_ctx *ctx, smm_plan *plan,
                              int64_t *c_indptr, int32_t *c_indices, double *c_data);
+/* The same with int64 column indices in the host array (widened while the chunks are copied out): for
+ * results with nnz >= 2^31, where a scipy CSR needs indptr and indices of one (64-bit) dtype -- which
+ * the reference's int32 structs cannot represent at all. */
+int  smm_spgemm_numeric_host_i64(smm_ctx *ctx, smm_plan *plan,
+                                 int64_t *c_indptr, int64_t *c_indices, double *c_data);
 /* Only the int64 row pointer of the planned product (device->host, a.rows+1 entries). */
 int  smm_plan_indptr_host(smm_ctx *ctx, smm_plan *plan, int64_t *c_indptr);
 int64_t smm_plan_nnz(const smm_plan *plan);

@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("SMM_LIB_PATH") or os.path.join(_HERE, "lib", "libsmm_
 SMM_SYMMETRIC = 1
 SMM_FULL_MATRIX = 2
 SMM_EXACT = 4
+SMM_MIRROR = 8
 
 _c_i64 = ctypes.c_int64
 _vp = ctypes.c_void_p
@@ -50,6 +51,7 @@ V2_PROTOTYPES = {
     "smm_spgemm_symbolic": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _c_i64, _pp, ctypes.POINTER(_c_i64)]),
     "smm_spgemm_numeric": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "smm_spgemm_numeric_host": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "smm_spgemm_numeric_host_i64": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "smm_plan_indptr_host": (ctypes.c_int, [_vp, _vp, _vp]),
     "smm_plan_nnz": (_c_i64, [_vp]),
     "smm_plan_destroy": (None, [_vp]),

@@ -6,13 +6,19 @@
 #include "smm_slab.hpp"
 #include "../../include/smm_hip.h"
 
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace smm;
@@ -73,6 +79,11 @@ struct smm_ctx {
     std::map<void *, size_t> live;        // blocks handed out
     std::vector<TimedLaunch> launches;
     std::map<std::string, std::pair<double, int64_t>> totals;
+    // result download (download() below): ring of pinned bounce buffers, allocated on first use
+    static constexpr int PIN_SLOTS = 8;
+    static constexpr size_t PIN_BYTES = (size_t)32 << 20;
+    void *pin[PIN_SLOTS] = {nullptr};
+    hipEvent_t pin_ev[PIN_SLOTS] = {nullptr};
     unsigned *d_flags = nullptr;     // [0] validation flags; +64: int -1 and +128: double 0 read by idle lanes
     std::recursive_mutex mu;         // every entry point that touches the context takes it: calls from
                                      // several host threads on one context serialise (one stream anyway)
@@ -199,6 +210,10 @@ extern "C" void smm_ctx_destroy(smm_ctx *c)
     for (auto &b : c->pool) (void)hipFree(b.p);
     for (auto &kv : c->live) (void)hipFree(kv.first);
     (void)hipFree(c->d_flags);
+    for (int i = 0; i < smm_ctx::PIN_SLOTS; ++i) {
+        if (c->pin[i]) (void)hipHostFree(c->pin[i]);
+        if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -301,6 +316,105 @@ extern "C" int smm_ctx_tune_shared(smm_ctx *c, int lds_cols, int waves)
         if (waves != 4 && waves != 8 && waves != 16) return fail(SMM_ERR_INVALID, "waves must be 4, 8 or 16");
         c->waves_shared = waves;
     }
+    return SMM_OK;
+}
+
+// ------------------------------------------------------------------------------ result download
+// Device -> host copy of a result into the caller's (pageable, usually freshly allocated) array
+// (reference: sparsemat_to_csr / darray_to_numpy copy the result out, matrix_ops.py:205-240).  One big
+// hipMemcpy into such memory runs at the speed of ONE thread taking page faults 4 KB at a time.  Here:
+//  * the destination is first advised to use transparent huge pages (512x fewer faults where the kernel
+//    allows it; harmless where it does not);
+//  * chunks of 32 MB travel by DMA into a ring of pinned buffers on the context's stream, and a few host
+//    threads copy finished chunks into the destination in parallel -- so the faults are taken by several
+//    threads and overlap with the DMA of the following chunks.
+// Small results take the plain copy (the pipeline's start-up costs more than it saves below ~64 MB).
+// widen: the source holds int32, the destination receives int64 (CSR column indices of a result whose nnz
+// does not fit int32: scipy wants indptr and indices of one dtype); `bytes` counts SOURCE bytes.
+static int download(smm_ctx *c, void *dst, const void *src_dev, size_t bytes, bool widen = false)
+{
+    if (bytes == 0) return SMM_OK;
+    if (bytes < ((size_t)64 << 20) && !widen) {
+        HIPCHK(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return SMM_OK;
+    }
+    constexpr int R = smm_ctx::PIN_SLOTS;
+    constexpr size_t CH = smm_ctx::PIN_BYTES;
+    for (int i = 0; i < R; ++i) {
+        if (!c->pin[i]) {
+            if (hipHostMalloc(&c->pin[i], CH, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                c->pin[i] = nullptr;
+                if (widen) return fail(SMM_ERR_ALLOC, "hipHostMalloc of the download ring failed");
+                HIPCHK(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));   // no pinned memory: plain copy
+                HIPCHK(hipStreamSynchronize(c->stream));
+                return SMM_OK;
+            }
+            HIPCHK(hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
+        }
+    }
+    {   // huge pages for the page-aligned interior of the destination
+        const size_t pg = (size_t)2 << 20;
+        const size_t dbytes = widen ? 2 * bytes : bytes;
+        const uintptr_t lo = ((uintptr_t)dst + pg - 1) & ~(uintptr_t)(pg - 1), hi = ((uintptr_t)dst + dbytes) & ~(uintptr_t)(pg - 1);
+        if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);
+    }
+    const size_t nchunks = (bytes + CH - 1) / CH;
+    const int W = (int)std::min<size_t>(4, nchunks);
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<char> issued(nchunks, 0), copied(nchunks, 0);
+    hipError_t worker_err = hipSuccess;
+    auto worker = [&](int w) {
+        (void)hipSetDevice(c->device);
+        for (size_t i = (size_t)w; i < nchunks; i += (size_t)W) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return issued[i] != 0; });
+                if (issued[i] == 2) return;                         // the issuing side failed: stop
+            }
+            const hipError_t e = hipEventSynchronize(c->pin_ev[i % R]);
+            const size_t off = i * CH, len = std::min(CH, bytes - off);
+            if (e == hipSuccess) {
+                if (!widen) memcpy((char *)dst + off, c->pin[i % R], len);
+                else {
+                    const int32_t *sp = (const int32_t *)c->pin[i % R];
+                    int64_t *dp = (int64_t *)dst + off / sizeof(int32_t);
+                    for (size_t k = 0; k < len / sizeof(int32_t); ++k) dp[k] = sp[k];
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (e != hipSuccess) worker_err = e;
+                copied[i] = 1;
+            }
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> threads;
+    for (int w = 0; w < W; ++w) threads.emplace_back(worker, w);
+    hipError_t err = hipSuccess;
+    for (size_t i = 0; i < nchunks; ++i) {
+        if (i >= (size_t)R) {                                       // the slot's previous chunk must have left it
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return copied[i - R] != 0; });
+        }
+        const size_t off = i * CH, len = std::min(CH, bytes - off);
+        if (err == hipSuccess) err = hipMemcpyAsync(c->pin[i % R], (const char *)src_dev + off, len, hipMemcpyDeviceToHost, c->stream);
+        if (err == hipSuccess) err = hipEventRecord(c->pin_ev[i % R], c->stream);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            issued[i] = err == hipSuccess ? 1 : 2;
+            if (err != hipSuccess)
+                for (size_t k = i; k < nchunks; ++k) issued[k] = 2;
+        }
+        cv.notify_all();
+        if (err != hipSuccess) break;
+    }
+    for (auto &t : threads) t.join();
+    if (err == hipSuccess) err = worker_err;
+    if (err != hipSuccess) { (void)hipGetLastError(); return fail(SMM_ERR_HIP, "result download: %s", hipGetErrorString(err)); }
     return SMM_OK;
 }
 
@@ -1088,7 +1202,16 @@ extern "C" int smm_plan_indptr_host(smm_ctx *c, smm_plan *p, int64_t *c_indptr)
     return SMM_OK;
 }
 
+static int numeric_host(smm_ctx *c, smm_plan *p, int64_t *c_indptr, void *c_indices, double *c_data, bool wide);
 extern "C" int smm_spgemm_numeric_host(smm_ctx *c, smm_plan *p, int64_t *c_indptr, int32_t *c_indices, double *c_data)
+{
+    return numeric_host(c, p, c_indptr, c_indices, c_data, false);
+}
+extern "C" int smm_spgemm_numeric_host_i64(smm_ctx *c, smm_plan *p, int64_t *c_indptr, int64_t *c_indices, double *c_data)
+{
+    return numeric_host(c, p, c_indptr, c_indices, c_data, true);
+}
+static int numeric_host(smm_ctx *c, smm_plan *p, int64_t *c_indptr, void *c_indices, double *c_data, bool wide)
 {
     if (!c || !p || !c_indptr) return fail(SMM_ERR_INVALID, "NULL argument");
     CTX_LOCK(c);
@@ -1099,18 +1222,10 @@ extern "C" int smm_spgemm_numeric_host(smm_ctx *c, smm_plan *p, int64_t *c_indpt
     int rc = pool_get(c, (size_t)std::max<int64_t>(nnz, 1), &di);
     if (rc == SMM_OK) rc = pool_get(c, (size_t)std::max<int64_t>(nnz, 1), &dv);
     if (rc == SMM_OK) rc = smm_spgemm_numeric(c, p, dp, di, dv);
-    if (rc == SMM_OK) {
-        hipError_t e = hipMemcpyAsync(c_indptr, dp, (p->m + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess && nnz > 0) {
-            if (!c_indices || !c_data) rc = fail(SMM_ERR_INVALID, "output arrays are NULL but nnz > 0");
-            else {
-                e = hipMemcpyAsync(c_indices, di, nnz * sizeof(int), hipMemcpyDeviceToHost, c->stream);
-                if (e == hipSuccess) e = hipMemcpyAsync(c_data, dv, nnz * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-            }
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess && rc == SMM_OK) rc = fail(SMM_ERR_HIP, "result download: %s", hipGetErrorString(e));
-    }
+    if (rc == SMM_OK && nnz > 0 && (!c_indices || !c_data)) rc = fail(SMM_ERR_INVALID, "output arrays are NULL but nnz > 0");
+    if (rc == SMM_OK) rc = download(c, c_indptr, dp, (size_t)(p->m + 1) * sizeof(int64_t));
+    if (rc == SMM_OK && nnz > 0) rc = download(c, c_indices, di, (size_t)nnz * sizeof(int), wide);
+    if (rc == SMM_OK && nnz > 0) rc = download(c, c_data, dv, (size_t)nnz * sizeof(double));
     (void)hipStreamSynchronize(c->stream);
     pool_free(c, dp); pool_free(c, di); pool_free(c, dv);
     return rc;
@@ -1159,13 +1274,30 @@ static int dense_into(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t row
     return SMM_OK;
 }
 
+static int mirror_upper(smm_ctx *c, int64_t n, double *d_c, int64_t ldc)
+{
+    if (n <= 1) return SMM_OK;
+    const int64_t tiles = (n + 63) / 64;
+    const int64_t pairs = tiles * (tiles + 1) / 2;
+    if (pairs > 0x7fffffff) return fail(SMM_ERR_INVALID, "matrix too large for the mirror epilogue");
+    LAUNCH(c, "smm_mirror_upper", smm_mirror_upper, pairs, 256, 0, (int)n, d_c, ldc);
+    LAUNCH_CHECK();
+    return SMM_OK;
+}
+
 extern "C" int smm_spgemm_dense(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t a_row_offset, double *d_c)
 {
     if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
     CTX_LOCK(c);
     CHK(check_pair(c, a, b));
     if (!d_c && a->rows * b->cols > 0) return fail(SMM_ERR_INVALID, "d_c is NULL");
-    return dense_into(c, a, b, flags, a_row_offset, d_c, b->cols);
+    if (flags & SMM_MIRROR) {
+        if (!(flags & SMM_SYMMETRIC) || a->rows != b->cols || a_row_offset != 0)
+            return fail(SMM_ERR_INVALID, "SMM_MIRROR needs SMM_SYMMETRIC and the whole square result (no row shard)");
+    }
+    CHK(dense_into(c, a, b, flags, a_row_offset, d_c, b->cols));
+    if (flags & SMM_MIRROR) CHK(mirror_upper(c, b->cols, d_c, b->cols));
+    return SMM_OK;
 }
 
 extern "C" int smm_spgemm_dense_host(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t a_row_offset, double *out)
@@ -1179,11 +1311,7 @@ extern "C" int smm_spgemm_dense_host(smm_ctx *c, smm_csr *a, smm_csr *b, int fla
     double *d = nullptr;
     CHK(pool_get(c, (size_t)total, &d));
     int rc = smm_spgemm_dense(c, a, b, flags, a_row_offset, d);
-    if (rc == SMM_OK) {
-        hipError_t e = hipMemcpyAsync(out, d, total * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) rc = fail(SMM_ERR_HIP, "result download: %s", hipGetErrorString(e));
-    }
+    if (rc == SMM_OK) rc = download(c, out, d, (size_t)total * sizeof(double));
     (void)hipStreamSynchronize(c->stream);
     pool_free(c, d);
     return rc;
@@ -1202,8 +1330,10 @@ extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags,
     if (q->cols > K) return fail(SMM_ERR_INVALID, "Q has more columns (%lld) than H (%lld)", (long long)q->cols, (long long)K);
     if (row_begin < 0 || row_end > n || row_begin > row_end) return fail(SMM_ERR_INVALID, "bad row range");
     const bool full = flags & SMM_FULL_MATRIX;
-    if (full && (row_begin != 0 || row_end != n))
-        return fail(SMM_ERR_INVALID, "SMM_FULL_MATRIX needs the whole row range [0,n)");
+    const bool mirror = (flags & SMM_MIRROR) != 0;
+    if (full && mirror) return fail(SMM_ERR_INVALID, "SMM_FULL_MATRIX and SMM_MIRROR exclude each other");
+    if ((full || mirror) && (row_begin != 0 || row_end != n))
+        return fail(SMM_ERR_INVALID, "SMM_FULL_MATRIX / SMM_MIRROR need the whole row range [0,n)");
     const int64_t nr = row_end - row_begin;
     if (nr == 0 || n == 0) return SMM_OK;
     if (!d_c) return fail(SMM_ERR_INVALID, "d_c is NULL");
@@ -1235,6 +1365,7 @@ extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags,
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         pool_free(c, T);
         if (e != hipSuccess) return fail(SMM_ERR_HIP, "triple product: %s", hipGetErrorString(e));
+        if (mirror) CHK(mirror_upper(c, n, d_c, n));
         return SMM_OK;
     }
     constexpr int NW = 16;
@@ -1263,6 +1394,7 @@ extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags,
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // T returns to the pool below
     pool_free(c, T);
     if (e != hipSuccess) return fail(SMM_ERR_HIP, "triple product: %s", hipGetErrorString(e));
+    if (mirror) CHK(mirror_upper(c, n, d_c, n));
     return SMM_OK;
 }
 
@@ -1277,11 +1409,7 @@ extern "C" int smm_triple_product_host(smm_ctx *c, smm_csr *h, smm_csr *q, int f
     double *d = nullptr;
     CHK(pool_get(c, (size_t)nr * n, &d));
     int rc = smm_triple_product(c, h, q, flags, row_begin, row_end, d);
-    if (rc == SMM_OK) {
-        hipError_t e = hipMemcpyAsync(out, d, nr * n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) rc = fail(SMM_ERR_HIP, "result download: %s", hipGetErrorString(e));
-    }
+    if (rc == SMM_OK) rc = download(c, out, d, (size_t)nr * (size_t)n * sizeof(double));
     (void)hipStreamSynchronize(c->stream);
     pool_free(c, d);
     return rc;

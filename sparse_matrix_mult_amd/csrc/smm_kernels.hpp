@@ -1490,4 +1490,29 @@ __global__ __launch_bounds__(256) void smm_triple_mirror(int n, double *__restri
     C[(int64_t)b * ldc + a] = v;
 }
 
+// Mirror epilogue: the lower triangle of an n x n upper-triangle result becomes the mirror
+// image of the upper one (what a caller of symmetric=True / compute_full_matrix=0 needs to use the result
+// as a full matrix; the reference's own compute_full_matrix=1 doubles the off-diagonal instead).
+// Tiles of 64 x 64 through LDS so that both the read and the write are row-contiguous.
+__global__ __launch_bounds__(256) void smm_mirror_upper(int n, double *__restrict__ C, int64_t ldc)
+{
+    __shared__ double t[64][65];
+    const int tiles = (n + 63) / 64;
+    // block b -> tile pair (ti <= tj) of the upper triangle, row-major over pairs
+    int64_t b = blockIdx.x;
+    int ti = 0;
+    while (b >= tiles - ti) { b -= tiles - ti; ++ti; }
+    const int tj = ti + (int)b;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;     // 4 rows per pass
+    for (int r = ty; r < 64; r += 4) {
+        const int a = ti * 64 + r, c = tj * 64 + tx;
+        t[r][tx] = (a < n && c < n) ? C[(int64_t)a * ldc + c] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int a = tj * 64 + r, c = ti * 64 + tx;            // target (a, c) = source (c, a)
+        if (a < n && c < n && a > c) C[(int64_t)a * ldc + c] = t[tx][r];
+    }
+}
+
 }  // namespace smm

@@ -9,14 +9,15 @@ import threading
 
 import numpy as np
 
-from ._lib import SMM_EXACT, SMM_FULL_MATRIX, SMM_SYMMETRIC, SmmError, SmmLibrary, check
+from ._lib import SMM_EXACT, SMM_FULL_MATRIX, SMM_MIRROR, SMM_SYMMETRIC, SmmError, SmmLibrary, check
 
 __all__ = ["Context", "DeviceCSR", "default_context", "SmmError",
-           "SMM_SYMMETRIC", "SMM_FULL_MATRIX", "SMM_EXACT"]
+           "SMM_SYMMETRIC", "SMM_FULL_MATRIX", "SMM_EXACT", "SMM_MIRROR"]
 
 
-def _flags(symmetric=False, exact=False, full=False):
-    return (SMM_SYMMETRIC if symmetric else 0) | (SMM_EXACT if exact else 0) | (SMM_FULL_MATRIX if full else 0)
+def _flags(symmetric=False, exact=False, full=False, mirror=False):
+    return ((SMM_SYMMETRIC if symmetric else 0) | (SMM_EXACT if exact else 0) | (SMM_FULL_MATRIX if full else 0) |
+            (SMM_MIRROR if mirror else 0))
 
 
 def _ptr(arr):
@@ -134,15 +135,19 @@ class Context:
                                                      ctypes.byref(plan), ctypes.byref(nnz)))
         return Plan(self, plan, a, b, nnz.value)
 
-    def spgemm_host(self, a, b, symmetric=False, row_offset=0, exact=False):
-        """(indptr int64, indices int32, data float64) numpy arrays, reference (first-touch) order."""
+    def spgemm_host(self, a, b, symmetric=False, row_offset=0, exact=False, index_dtype=None):
+        """(indptr int64, indices int32 -- int64 when nnz >= 2^31 or index_dtype says so --, data float64)
+        numpy arrays, reference (first-touch) order."""
         plan = self.spgemm_plan(a, b, symmetric, row_offset, exact)
         try:
+            # nnz >= 2^31 (BASELINE configs[1]: 2.48e9): int64 column indices, like the row pointer -- scipy's
+            # kernels take ONE index dtype per matrix; below that int32, as the reference returns
+            wide = plan.nnz > np.iinfo(np.int32).max if index_dtype is None else np.dtype(index_dtype) == np.int64
             indptr = np.empty(a.rows + 1, dtype=np.int64)
-            indices = np.empty(plan.nnz, dtype=np.int32)
+            indices = np.empty(plan.nnz, dtype=np.int64 if wide else np.int32)
             data = np.empty(plan.nnz, dtype=np.float64)
-            check(self.lib, self.lib.smm_spgemm_numeric_host(self.handle, plan.handle, _ptr(indptr), _ptr(indices),
-                                                             _ptr(data)))
+            fn = self.lib.smm_spgemm_numeric_host_i64 if wide else self.lib.smm_spgemm_numeric_host
+            check(self.lib, fn(self.handle, plan.handle, _ptr(indptr), _ptr(indices), _ptr(data)))
         finally:
             plan.close()
         return indptr, indices, data
@@ -162,29 +167,29 @@ class Context:
         return indptr, indices, data
 
     # ------------------------------------------------------------------ CSR x CSR -> dense
-    def dense_host(self, a, b, symmetric=False, row_offset=0, exact=False):
-        flags = _flags(symmetric, exact)
+    def dense_host(self, a, b, symmetric=False, row_offset=0, exact=False, mirror=False):
+        flags = _flags(symmetric, exact, mirror=mirror)
         out = np.empty((a.rows, b.cols), dtype=np.float64)
         check(self.lib, self.lib.smm_spgemm_dense_host(self.handle, a.handle, b.handle, flags, int(row_offset),
                                                        _ptr(out)))
         return out
 
-    def dense_into(self, a, b, d_ptr, symmetric=False, row_offset=0, exact=False):
-        flags = _flags(symmetric, exact)
+    def dense_into(self, a, b, d_ptr, symmetric=False, row_offset=0, exact=False, mirror=False):
+        flags = _flags(symmetric, exact, mirror=mirror)
         check(self.lib, self.lib.smm_spgemm_dense(self.handle, a.handle, b.handle, flags, int(row_offset),
                                                   ctypes.c_void_p(d_ptr)))
 
     # ------------------------------------------------------------------ H Q H^T
-    def triple_host(self, h, q, full=False, row_begin=0, row_end=None, exact=False):
+    def triple_host(self, h, q, full=False, row_begin=0, row_end=None, exact=False, mirror=False):
         row_end = h.rows if row_end is None else row_end
         out = np.empty((row_end - row_begin, h.rows), dtype=np.float64)
-        check(self.lib, self.lib.smm_triple_product_host(self.handle, h.handle, q.handle, _flags(False, exact, full),
+        check(self.lib, self.lib.smm_triple_product_host(self.handle, h.handle, q.handle, _flags(False, exact, full, mirror),
                                                          int(row_begin), int(row_end), _ptr(out)))
         return out
 
-    def triple_into(self, h, q, d_ptr, full=False, row_begin=0, row_end=None, exact=False):
+    def triple_into(self, h, q, d_ptr, full=False, row_begin=0, row_end=None, exact=False, mirror=False):
         row_end = h.rows if row_end is None else row_end
-        check(self.lib, self.lib.smm_triple_product(self.handle, h.handle, q.handle, _flags(False, exact, full),
+        check(self.lib, self.lib.smm_triple_product(self.handle, h.handle, q.handle, _flags(False, exact, full, mirror),
                                                     int(row_begin), int(row_end), ctypes.c_void_p(d_ptr)))
 
 

@@ -266,3 +266,63 @@ def test_legacy_symbols_honour_smm_exact(legacy, oracle, monkeypatch):
     legacy.destroy_darray(ctypes.byref(d)); legacy.destroy_sparsemat(ctypes.byref(out))
     for s in (a, b):
         legacy.destroy_sparsemat(ctypes.byref(s))
+
+
+# ---- operand cache: a repeated operand is neither uploaded nor re-indexed
+def test_operand_cache_skips_upload_and_tile_index(smm, oracle):
+    import sparse_matrix_mult_amd as pkg
+    from sparse_matrix_mult_amd.engine import default_context
+    ctx = default_context()
+    pkg.clear_cache()
+    old = pkg.set_operand_cache(4)
+    ctx.tune_hash(0, 0)                                   # every row through the tile kernels (they need the tile index)
+    try:
+        B = rand_csr(600, 700, 0.05, 2)
+        mats = [rand_csr(300, 600, 0.05, 10 + i) for i in range(3)]
+        ctx.timing(True); ctx.timing_reset()
+        first = smm(mats[0], B)
+        n_val, n_seg, n_loc = (ctx.kernel_time(k)[1] for k in ("smm_validate", "smm_segptr", "smm_loc16"))
+        assert n_val == 2 and n_seg >= 1                  # both operands validated, B indexed
+        for A in mats[1:]:                                # many A against one B (reference README.md:5,13)
+            C = smm(A, B)
+            want = oracle.sparse(arrays(A), arrays(B), 700)
+            assert np.array_equal(C.indptr, want[0]) and np.array_equal(C.indices, want[1])
+            assert np.allclose(C.data, want[2], rtol=1e-10, atol=0)
+        again = smm(mats[0], B)                           # both operands cached now
+        assert np.array_equal(again.indices, first.indices) and np.array_equal(again.data, first.data)
+        v2, s2, l2 = (ctx.kernel_time(k)[1] for k in ("smm_validate", "smm_segptr", "smm_loc16"))
+        assert (v2, s2, l2) == (n_val + 2, n_seg, n_loc)  # only the two new A's were validated; B untouched
+        # an operand edited in place where the sample looks is seen as a new one
+        B2 = B.copy(); B2.data[:] *= 2.0
+        assert np.allclose(smm(mats[0], B2).data, 2.0 * first.data, rtol=1e-12)
+        # switching the cache off goes back to upload-per-call
+        pkg.set_operand_cache(0)
+        before = ctx.kernel_time("smm_validate")[1]
+        smm(mats[0], B)
+        assert ctx.kernel_time("smm_validate")[1] == before + 2
+    finally:
+        ctx.timing(False)
+        ctx.tune_hash(256, 2048)
+        pkg.set_operand_cache(old)
+        pkg.clear_cache()
+
+
+def test_wide_index_result_is_a_usable_scipy_matrix(ctx, oracle):
+    """nnz >= 2^31 cannot be int32 (BASELINE configs[1] has 2.48e9): the host result then carries
+    int64 indptr AND indices.  The widening path is forced here on a small product and the matrix is used
+    the way a caller would (matvec, toarray, slicing); tests/test_gpu_baseline_configs.py covers the size."""
+    from sparse_matrix_mult_amd.matrix_ops import _result_csr
+    A, B = rand_csr(400, 300, 0.05, 1), rand_csr(300, 500, 0.05, 2)
+    a, b = ctx.csr_from_scipy(A), ctx.csr_from_scipy(B)
+    try:
+        narrow = ctx.spgemm_host(a, b, exact=True)
+        wide = ctx.spgemm_host(a, b, exact=True, index_dtype=np.int64)
+    finally:
+        a.close(); b.close()
+    assert narrow[1].dtype == np.int32 and wide[1].dtype == np.int64 and wide[0].dtype == np.int64
+    assert np.array_equal(narrow[1], wide[1]) and np.array_equal(narrow[2], wide[2])
+    C = _result_csr(*wide, (400, 500))
+    assert C.indptr.dtype == np.int64 and C.indices.dtype == np.int64
+    want = oracle.dense(arrays(A), arrays(B), 500)
+    x = np.random.default_rng(3).random(500)
+    assert np.allclose(C @ x, want @ x) and np.array_equal(C.toarray(), want) and np.array_equal(C[10:20].toarray(), want[10:20])

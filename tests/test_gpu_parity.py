@@ -375,3 +375,58 @@ def test_triple_unsorted_h_and_narrow_q(ctx, oracle, full):
     finally:
         h.close(); qd.close()
     assert np.array_equal(got.view(np.int64), want.view(np.int64))
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 200, 777])
+def test_mirror_epilogue_dense_and_triple(ctx, oracle, n):
+    """SURVEY 8f-2 (opt-in, not in the reference): the lower triangle becomes the mirror image of the
+    upper one on the device.  For C = A A^T both triangles hold the same products in the same order, so
+    the mirrored symmetric product equals the non-symmetric one bit for bit."""
+    A = rand_csr(n, max(1, n // 2 + 3), 0.2, 31)
+    if A.nnz == 0:
+        A = sp.csr_matrix(np.ones((n, max(1, n // 2 + 3))))
+    B = A.T.tocsr()
+    a, b = ctx.csr_from_scipy(A), ctx.csr_from_scipy(B)
+    try:
+        got = ctx.dense_host(a, b, symmetric=True, exact=True, mirror=True)
+        upper = ctx.dense_host(a, b, symmetric=True, exact=True)
+    finally:
+        a.close(); b.close()
+    want = oracle.dense(arrays(A), arrays(B), n, symmetric=False)
+    assert np.array_equal(got.view(np.int64), want.view(np.int64))
+    assert np.array_equal(np.triu(got).view(np.int64), upper.view(np.int64))
+    # triple product: upper triangle untouched, lower = its transpose
+    S = sp.random(A.shape[1], A.shape[1], density=0.1, format="csr", random_state=np.random.default_rng(32))
+    Q = (S + S.T).tocsr()
+    h, q = ctx.csr_from_scipy(A), ctx.csr_from_scipy(Q)
+    try:
+        got = ctx.triple_host(h, q, exact=True, mirror=True)
+    finally:
+        h.close(); q.close()
+    up = oracle.triple(arrays(A), arrays(Q), A.shape[1], 0)
+    assert np.array_equal(np.triu(got).view(np.int64), up.view(np.int64))
+    assert np.array_equal(got, got.T)
+    assert np.allclose(got, (A @ Q @ A.T).toarray(), rtol=1e-10, atol=1e-13)
+
+
+def test_mirror_through_the_python_api(oracle):
+    import sparse_matrix_mult_amd as pkg
+    A = rand_csr(150, 90, 0.15, 41)
+    S = sp.random(90, 90, density=0.1, format="csr", random_state=np.random.default_rng(42))
+    Q = (S + S.T).tocsr()
+    up = pkg.sparse_matrix_multiply(A, Q, use_triple_product=True)
+    full = pkg.sparse_matrix_multiply(A, Q, use_triple_product=True, compute_full_matrix='mirror')
+    assert np.array_equal(np.triu(full), up) and np.array_equal(full, full.T) and np.all(np.tril(up, -1) == 0.0)
+    with pytest.raises(ValueError):
+        pkg.sparse_matrix_multiply(A, A.T.tocsr(), compute_full_matrix='mirror')       # only for the triple product
+    old = pkg.set_full_symmetric(True)
+    try:
+        D = pkg.sparse_matrix_multiply(A, A.T.tocsr(), output_format='dense', symmetric=True)
+        assert np.array_equal(D, D.T) and np.allclose(D, (A @ A.T).toarray(), rtol=1e-10, atol=0)
+        assert np.array_equal(pkg.sparse_matrix_multiply(A, Q, use_triple_product=True), full)
+        C = pkg.sparse_matrix_multiply(A, A.T.tocsr(), output_format='sparse', symmetric=True)   # CSR stays upper
+        assert (sp.tril(C, -1)).nnz == 0
+    finally:
+        pkg.set_full_symmetric(old)
+    D = pkg.sparse_matrix_multiply(A, A.T.tocsr(), output_format='dense', symmetric=True)
+    assert np.all(np.tril(D, -1) == 0.0)                                                # default: reference behaviour
