@@ -414,6 +414,14 @@ def test_mirror_through_the_python_api(oracle):
     A = rand_csr(150, 90, 0.15, 41)
     S = sp.random(90, 90, density=0.1, format="csr", random_state=np.random.default_rng(42))
     Q = (S + S.T).tocsr()
+    old_exact = pkg.set_exact(True)                      # bitwise comparisons between separate calls below
+    try:
+        _mirror_api_checks(pkg, A, Q)
+    finally:
+        pkg.set_exact(old_exact)
+
+
+def _mirror_api_checks(pkg, A, Q):
     up = pkg.sparse_matrix_multiply(A, Q, use_triple_product=True)
     full = pkg.sparse_matrix_multiply(A, Q, use_triple_product=True, compute_full_matrix='mirror')
     assert np.array_equal(np.triu(full), up) and np.array_equal(full, full.T) and np.all(np.tril(up, -1) == 0.0)
