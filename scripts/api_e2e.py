@@ -1,5 +1,11 @@
-"""End-to-end timings through the drop-in Python API (scipy in, scipy/numpy out, PCIe included)
-on the orientation configs of BASELINE.md section 2."""
+"""End-to-end timings through the drop-in Python API (scipy in, scipy/numpy out, PCIe and result
+construction included).
+
+    python scripts/api_e2e.py            # the orientation configs of BASELINE.md section 2
+    python scripts/api_e2e.py big        # BASELINE configs[1] and [2]: 50 000 x 50 000, d = 0.01, -> CSR / dense
+
+`big` builds the operands on the device (synthetic.py) and hands them to the API as scipy matrices on
+the host; every call is timed cold (operand cache cleared) and warm (both operands cached)."""
 import json
 import sys
 import time
@@ -8,7 +14,42 @@ import numpy as np
 import scipy.sparse as sp
 
 sys.path.insert(0, ".")
+import sparse_matrix_mult_amd as pkg  # noqa: E402
 from sparse_matrix_mult_amd import sparse_matrix_multiply  # noqa: E402
+
+
+def timed(fn):
+    t0 = time.perf_counter()
+    out = fn()
+    return out, time.perf_counter() - t0
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "big":
+    import torch
+    from sparse_matrix_mult_amd.synthetic import gen_csr_device
+    dev = torch.device("cuda", 0)
+    n, d = 50000, 0.01
+    mats = []
+    for seed in (1, 2):
+        ip, ix, dv = (t.cpu().numpy() for t in gen_csr_device(torch, n, n, d, seed, dev))
+        mats.append(sp.csr_matrix((dv, ix, ip), shape=(n, n)))
+    torch.cuda.empty_cache()
+    A, B = mats
+    for fmt in ("sparse", "dense"):
+        res = {}
+        for label in ("cold", "warm", "warm2"):
+            if label == "cold":
+                pkg.clear_cache()
+            C, dt = timed(lambda: sparse_matrix_multiply(A, B, output_format=fmt))
+            res[label] = round(dt, 3)
+            if fmt == "sparse":
+                info = {"nnzC": int(C.nnz), "indices_dtype": str(C.indices.dtype), "indptr_dtype": str(C.indptr.dtype),
+                        "result_GB": round((C.data.nbytes + C.indices.nbytes + C.indptr.nbytes) / 1e9, 2)}
+            else:
+                info = {"result_GB": round(C.nbytes / 1e9, 2)}
+            del C
+        print(json.dumps({"config": f"{n}x{n} d={d} -> {fmt} through sparse_matrix_multiply()", "seconds": res, **info}), flush=True)
+    sys.exit(0)
 
 for n, d in ((1000, 0.05), (5000, 0.01), (10000, 0.005)):
     A = sp.random(n, n, density=d, format="csr", random_state=np.random.default_rng(1))

@@ -334,7 +334,8 @@ extern "C" int smm_ctx_tune_shared(smm_ctx *c, int lds_cols, int waves)
 static int download(smm_ctx *c, void *dst, const void *src_dev, size_t bytes, bool widen = false)
 {
     if (bytes == 0) return SMM_OK;
-    if (bytes < ((size_t)64 << 20) && !widen) {
+    static const bool plain = getenv("SMM_DOWNLOAD_PLAIN") != nullptr;      // A/B switch for scripts/api_e2e.py
+    if ((bytes < ((size_t)64 << 20) || plain) && !widen) {
         HIPCHK(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         return SMM_OK;
