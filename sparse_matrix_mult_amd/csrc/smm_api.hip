@@ -328,14 +328,15 @@ extern "C" int smm_ctx_tune_shared(smm_ctx *c, int lds_cols, int waves)
 //  * chunks of 32 MB travel by DMA into a ring of pinned buffers on the context's stream, and a few host
 //    threads copy finished chunks into the destination in parallel -- so the faults are taken by several
 //    threads and overlap with the DMA of the following chunks.
-// Small results take the plain copy (the pipeline's start-up costs more than it saves below ~64 MB).
+// Small results take the plain copy (measured: at 118 MB the pipeline's start-up still cost 5 ms more than it
+// saved, at 265 MB it was ahead).
 // widen: the source holds int32, the destination receives int64 (CSR column indices of a result whose nnz
 // does not fit int32: scipy wants indptr and indices of one dtype); `bytes` counts SOURCE bytes.
 static int download(smm_ctx *c, void *dst, const void *src_dev, size_t bytes, bool widen = false)
 {
     if (bytes == 0) return SMM_OK;
     static const bool plain = getenv("SMM_DOWNLOAD_PLAIN") != nullptr;      // A/B switch for scripts/api_e2e.py
-    if ((bytes < ((size_t)64 << 20) || plain) && !widen) {
+    if ((bytes < ((size_t)256 << 20) || plain) && !widen) {
         HIPCHK(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         return SMM_OK;
