@@ -94,9 +94,6 @@ int  smm_ctx_tune_hash(smm_ctx *ctx, int small_max, int medium_max);
  * ws = slab width in columns (0 = sized so that one slab of B is L2-resident); rows_per_wave 2 or 4
  * (0 keeps the setting).  Results do not depend on any of it beyond default-mode rounding. */
 int  smm_ctx_tune_slab(smm_ctx *ctx, int mode, int ws, int rows_per_wave);
-/* Stage 2 of the triple product: 0 = row-lane kernel (default), 1 = the sliced-ELL kernel it replaced
- * (kept for comparison).  Results are identical bit for bit with SMM_EXACT. */
-int  smm_ctx_tune_triple(smm_ctx *ctx, int kernel);
 
 /* ------------------------------------------------------------------ operands
  * Replaces create_sparsemat + the three memmoves of csr_to_sparsemat

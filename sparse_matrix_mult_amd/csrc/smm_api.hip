@@ -4,7 +4,6 @@
 // no device every entry point fails with SMM_ERR_NO_DEVICE.
 #include "smm_kernels.hpp"
 #include "smm_slab.hpp"
-#include "smm_triple.hpp"
 #include "../../include/smm_hip.h"
 
 #include <sys/mman.h>
@@ -75,7 +74,6 @@ struct smm_ctx {
     // they can run; ws = slab width (0 = sized so that one slab of B is ~3 MB, L2-resident);
     // rows per wave 2 or 4 (8 waves per workgroup: 16 or 32 rows per block)
     int slab_mode = 0, slab_ws = 0, slab_rw = 4;
-    int triple_kernel = 0;   // stage 2 of the triple product: 0 = row-lane kernel (smm_triple.hpp), 1 = the sliced-ELL kernel
     int n_cu = 256;
     std::vector<PoolBlock> pool;          // free blocks
     std::map<void *, size_t> live;        // blocks handed out
@@ -306,14 +304,6 @@ extern "C" int smm_ctx_tune_slab(smm_ctx *c, int mode, int ws, int rows_per_wave
     if (rows_per_wave) c->slab_rw = rows_per_wave;
     return SMM_OK;
 }
-extern "C" int smm_ctx_tune_triple(smm_ctx *c, int kernel)
-{
-    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
-    CTX_LOCK(c);
-    if (kernel != 0 && kernel != 1) return fail(SMM_ERR_INVALID, "triple kernel must be 0 (row-lane) or 1 (sliced ELL)");
-    c->triple_kernel = kernel;
-    return SMM_OK;
-}
 extern "C" int smm_ctx_tune_shared(smm_ctx *c, int lds_cols, int waves)
 {
     if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
@@ -451,9 +441,6 @@ struct smm_csr {
     // sliced-ELL copy for triple-product stage 2 (chunk width ell_chunk)
     int ell_chunk = 0, ell_nchunks = 0; int *ell_len = nullptr; int64_t *ell_off = nullptr;
     short *ell_col = nullptr; double *ell_val = nullptr;
-    // blocks-of-four copy for the row-lane stage 2 (smm_triple.hpp), chunk width kell_cw, kell_kpad rows k
-    int kell_cw = 0, kell_kpad = 0, kell_nchunks = 0, kell_blocks = 0;
-    int *kell_ptr = nullptr, *kell_off = nullptr; double *kell_val = nullptr;
 };
 
 static int validate(smm_ctx *c, smm_csr *m)
@@ -542,7 +529,6 @@ extern "C" void smm_csr_destroy(smm_csr *m)
     for (auto &e : m->locs) (void)hipFree(e.loc);
     for (auto &e : m->slabs) { (void)hipFree(e.soff); (void)hipFree(e.scol); (void)hipFree(e.sval); }
     (void)hipFree(m->ell_len); (void)hipFree(m->ell_off); (void)hipFree(m->ell_col); (void)hipFree(m->ell_val);
-    (void)hipFree(m->kell_ptr); (void)hipFree(m->kell_off); (void)hipFree(m->kell_val);
     delete m;
 }
 extern "C" int64_t smm_csr_rows(const smm_csr *m) { return m ? m->rows : -1; }
@@ -877,62 +863,6 @@ static int ensure_slab(smm_ctx *c, smm_csr *b, const SlabGeom &g, const smm_csr:
     if (rc != SMM_OK) { (void)hipFree(e.soff); (void)hipFree(e.scol); (void)hipFree(e.sval); return rc; }
     b->slabs.push_back(e);
     *out = &b->slabs.back();
-    return SMM_OK;
-}
-
-// Blocks-of-four copy of H for the row-lane stage 2 (smm_triple.hpp), cached on the handle.
-constexpr int TRL_NW = 16, TRL_NKW = 28, TRL_KG = TRL_NW * TRL_NKW, TRL_CW = 256;
-static int ensure_kell(smm_ctx *c, smm_csr *h, int cw, int kpad)
-{
-    if (h->kell_val && h->kell_cw == cw && h->kell_kpad == kpad) return SMM_OK;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    (void)hipFree(h->kell_ptr); (void)hipFree(h->kell_off); (void)hipFree(h->kell_val);
-    h->kell_ptr = nullptr; h->kell_off = nullptr; h->kell_val = nullptr; h->kell_cw = 0;
-    const int nchunks = (int)((h->cols + cw - 1) / cw);
-    Geom gh; gh.nw = 1; gh.nct = nchunks; gh.wf = cw; gh.wc = cw; gh.n_ft = nchunks;
-    const int *hseg = nullptr;
-    CHK(ensure_seg(c, h, gh, &hseg));
-    const int64_t cells = (int64_t)nchunks * kpad;
-    if (cells + 1 >= INT32_MAX) return fail(SMM_ERR_INVALID, "triple product: too many (chunk, row) cells");
-    int *cnt = nullptr; int64_t *off64 = nullptr;
-    CHK(pool_get(c, (size_t)cells, &cnt));
-    int rc = pool_get(c, (size_t)cells + 1, &off64);
-    if (rc != SMM_OK) { pool_free(c, cnt); return rc; }
-    LAUNCH(c, "smm_kell_count", smm_kell_count, (cells + 255) / 256, 256, 0, (int)h->rows, kpad, nchunks, hseg, cnt);
-    rc = scan_launch<int>(c, cells, cnt, off64);
-    int64_t blocks = 0;
-    if (rc == SMM_OK) {
-        hipError_t e = hipMemcpyAsync(&blocks, off64 + cells, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) rc = fail(SMM_ERR_HIP, "kell build: %s", hipGetErrorString(e));
-    }
-    if (rc == SMM_OK && blocks + 1 >= INT32_MAX / 4) rc = fail(SMM_ERR_INVALID, "triple product: H too large for the block copy");
-    if (rc == SMM_OK &&
-        (hipMalloc((void **)&h->kell_ptr, (size_t)(cells + 1) * sizeof(int)) != hipSuccess ||
-         hipMalloc((void **)&h->kell_off, (size_t)(blocks + 1) * 4 * sizeof(int)) != hipSuccess ||
-         hipMalloc((void **)&h->kell_val, (size_t)(blocks + 1) * 4 * sizeof(double)) != hipSuccess))
-        rc = fail(SMM_ERR_ALLOC, "hipMalloc of the block copy of H (%lld blocks) failed", (long long)blocks);
-    if (rc == SMM_OK) {
-        LAUNCH(c, "smm_narrow32", smm_narrow32, std::min<int64_t>((cells + 256) / 256, 65536), 256, 0, cells + 1, (const int64_t *)off64, h->kell_ptr);
-        // the spare block at the end (prefetches past the last block read it): zero column, 0.0
-        const int zoff = cw * TR_COLSTRIDE * 8;
-        const int spare_off[4] = {zoff, zoff, zoff, zoff};
-        const double spare_val[4] = {0.0, 0.0, 0.0, 0.0};
-        hipError_t e = hipMemcpyAsync(h->kell_off + (size_t)blocks * 4, spare_off, sizeof(spare_off), hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(h->kell_val + (size_t)blocks * 4, spare_val, sizeof(spare_val), hipMemcpyHostToDevice, c->stream);
-        LAUNCH(c, "smm_kell_fill", smm_kell_fill, (cells + 255) / 256, 256, 0, (int)h->rows, kpad, nchunks, cw, hseg, h->idx, h->val,
-               (const int *)h->kell_ptr, h->kell_off, h->kell_val);
-        if (e == hipSuccess) e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) rc = fail(SMM_ERR_HIP, "kell build: %s", hipGetErrorString(e));
-    }
-    pool_free(c, cnt); pool_free(c, off64);
-    if (rc != SMM_OK) {
-        (void)hipFree(h->kell_ptr); (void)hipFree(h->kell_off); (void)hipFree(h->kell_val);
-        h->kell_ptr = nullptr; h->kell_off = nullptr; h->kell_val = nullptr;
-        return rc;
-    }
-    h->kell_cw = cw; h->kell_kpad = kpad; h->kell_nchunks = nchunks; h->kell_blocks = (int)blocks;
     return SMM_OK;
 }
 
@@ -1435,37 +1365,6 @@ extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags,
         if (full) LAUNCH(c, "smm_triple_mirror", smm_triple_mirror, (n * n + 255) / 256, 256, 0, (int)n, d_c, n);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        pool_free(c, T);
-        if (e != hipSuccess) return fail(SMM_ERR_HIP, "triple product: %s", hipGetErrorString(e));
-        if (mirror) CHK(mirror_upper(c, n, d_c, n));
-        return SMM_OK;
-    }
-    if (c->triple_kernel == 0) {
-        // row-lane kernel: lanes = 64 rows of T, the entries of H wave-uniform (smm_triple.hpp)
-        const int cw = (int)std::min<int64_t>(TRL_CW, K);
-        const int n_kg = (int)((n + TRL_KG - 1) / TRL_KG);
-        rc = ensure_kell(c, h, cw, n_kg * TRL_KG);
-        if (rc != SMM_OK) { pool_free(c, T); return rc; }
-        RowLaneArgs R{};
-        R.n = (int)n; R.K = (int)K; R.cw = cw; R.nchunks = h->kell_nchunks; R.kpad = n_kg * TRL_KG;
-        R.n_rb = (int)((nr + 63) / 64); R.n_kg = n_kg;
-        const int64_t units = (int64_t)R.n_rb * R.n_kg;
-        R.cpx = (int)((units + 7) / 8);
-        R.row_begin = row_begin; R.row_end = row_end; R.full = full ? 1 : 0;
-        R.blkptr = h->kell_ptr; R.boff = h->kell_off; R.bval = h->kell_val; R.last_block = h->kell_blocks;
-        R.T = T; R.C = d_c; R.ldc = n;
-        const size_t lds = (size_t)(cw + 1) * TR_COLSTRIDE * sizeof(double);
-        const bool fma = !(flags & SMM_EXACT);
-        const void *kern = fma ? (const void *)smm_triple_rows<TRL_NW, TRL_NKW, true> : (const void *)smm_triple_rows<TRL_NW, TRL_NKW, false>;
-        hipError_t e = hipSuccess;
-        if (lds > 64 * 1024) e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) {
-            if (fma) LAUNCH(c, "smm_triple_rows", (smm_triple_rows<TRL_NW, TRL_NKW, true>), (int64_t)R.cpx * 8, TRL_NW * 64, lds, R);
-            else     LAUNCH(c, "smm_triple_rows", (smm_triple_rows<TRL_NW, TRL_NKW, false>), (int64_t)R.cpx * 8, TRL_NW * 64, lds, R);
-            if (full) LAUNCH(c, "smm_triple_mirror", smm_triple_mirror, (n * n + 255) / 256, 256, 0, (int)n, d_c, n);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // T returns to the pool below
         pool_free(c, T);
         if (e != hipSuccess) return fail(SMM_ERR_HIP, "triple product: %s", hipGetErrorString(e));
         if (mirror) CHK(mirror_upper(c, n, d_c, n));

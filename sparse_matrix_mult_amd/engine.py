@@ -77,10 +77,6 @@ class Context:
         rows_per_wave 2 or 4."""
         check(self.lib, self.lib.smm_ctx_tune_slab(self.handle, int(mode), int(ws), int(rows_per_wave)))
 
-    def tune_triple(self, kernel=0):
-        """Stage 2 of the triple product: 0 = row-lane kernel, 1 = sliced-ELL kernel."""
-        check(self.lib, self.lib.smm_ctx_tune_triple(self.handle, int(kernel)))
-
     def timing(self, enable=True):
         check(self.lib, self.lib.smm_ctx_timing(self.handle, 1 if enable else 0))
 
