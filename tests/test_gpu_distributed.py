@@ -23,7 +23,7 @@ def _worker(rank, world, port, ret):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
     from oracle import oracle
-    from sparse_matrix_mult_amd.distributed import spgemm_row_sharded
+    from sparse_matrix_mult_amd.distributed import dense_row_sharded, spgemm_row_sharded, triple_row_sharded
     from sparse_matrix_mult_amd.engine import Context
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -40,10 +40,42 @@ def _worker(rank, world, port, ret):
             ok &= np.array_equal(gp.cpu().numpy(), want[0])
             ok &= np.array_equal(li.cpu().numpy(), want[1][want[0][r0]:want[0][r1]])
             ok &= np.allclose(lv.cpu().numpy(), want[2][want[0][r0]:want[0][r1]], rtol=1e-10, atol=0)
+            # dense_nosym / dense_sym row blocks, one all_gather_into_tensor of padded tiles
+            D = dense_row_sharded(ctx, A, B, dist, symmetric=symmetric, exact=True)
+            ok &= np.array_equal(D.cpu().numpy(), oracle.dense(arrays(A), arrays(B), 333, symmetric=symmetric))
+            (d0, d1), blk = dense_row_sharded(ctx, A, B, dist, symmetric=symmetric, gather=False, exact=True)
+            ok &= tuple(blk.shape) == (d1 - d0, 333)
+        # triple product: row blocks balanced by sum(n - i)
+        import scipy.sparse as sp
+        H = rand_csr(190, 260, 0.06, 3)
+        S = sp.random(260, 260, density=0.03, format="csr", random_state=np.random.default_rng(4))
+        Q = (S + S.T).tocsr()
+        T = triple_row_sharded(ctx, H, Q, dist, exact=True)
+        ok &= np.array_equal(T.cpu().numpy(), oracle.triple(arrays(H), arrays(Q), 260, 0))
         ret[rank] = bool(ok)
     finally:
         ctx.close()
         dist.destroy_process_group()
+
+
+def test_bench_launches_its_own_ranks_and_gathers(tmp_path):
+    """`python bench.py --gpus 2` with no launcher starts its ranks itself (fresh child processes) and rank 0
+    prints one JSON line with n_gpus = 2.  Rehearsal mode: both ranks on GPU 0 over gloo -- the plumbing of the
+    N > 1 path (self-launch, shard, exchange step, --gather's all-gatherv), not a performance result."""
+    import json
+    import subprocess
+    env = dict(os.environ, SMM_BENCH_REHEARSAL="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    for extra in ([], ["--gather"]):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                              "--rows", "3000", "--cols", "6000", "--density", "0.004", "--no-cpu"] + extra,
+                             env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == 2 and line["value"] > 0 and line["unit"] == "nnz/s"
+        assert ("all-gatherv" in line["config"]["workload"]) == bool(extra)
 
 
 def test_two_ranks_reassemble_the_single_device_csr():
