@@ -94,6 +94,10 @@ int  smm_ctx_tune_hash(smm_ctx *ctx, int small_max, int medium_max);
  * ws = slab width in columns (0 = sized so that one slab of B is L2-resident); rows_per_wave 2 or 4
  * (0 keeps the setting).  Results do not depend on any of it beyond default-mode rounding. */
 int  smm_ctx_tune_slab(smm_ctx *ctx, int mode, int ws, int rows_per_wave);
+/* 1 (default): products whose B has < 65535 columns run the symbolic phase on uint16 -- a 16-bit copy of
+ * B's column indices (cached on the operand) and 16-bit ordered lists: half the bytes of that phase's gather
+ * and of the list traffic.  0: always int32.  Results are identical. */
+int  smm_ctx_tune_narrow(smm_ctx *ctx, int enable);
 
 /* ------------------------------------------------------------------ operands
  * Replaces create_sparsemat + the three memmoves of csr_to_sparsemat

@@ -74,6 +74,7 @@ struct smm_ctx {
     // they can run; ws = slab width (0 = sized so that one slab of B is ~3 MB, L2-resident);
     // rows per wave 2 or 4 (8 waves per workgroup: 16 or 32 rows per block)
     int slab_mode = 0, slab_ws = 0, slab_rw = 4;
+    int narrow_idx = 1;      // 1: operands with < 65535 columns go through the symbolic phase as uint16 (column stream and lists)
     int n_cu = 256;
     std::vector<PoolBlock> pool;          // free blocks
     std::map<void *, size_t> live;        // blocks handed out
@@ -178,6 +179,7 @@ extern "C" int smm_ctx_create(int device, void *hip_stream, smm_ctx **out)
                     prop.gcnArchName);
     smm_ctx *c = new smm_ctx();
     c->device = device;
+    if (const char *e = getenv("SMM_NARROW_IDX")) c->narrow_idx = atoi(e) != 0;     // A/B switch (scripts/ab_env.sh)
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hip_stream == SMM_STREAM_DEFAULT) { c->stream = nullptr; c->own_stream = false; }   // the device's null stream
     else if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
@@ -302,6 +304,13 @@ extern "C" int smm_ctx_tune_slab(smm_ctx *c, int mode, int ws, int rows_per_wave
     c->slab_mode = mode;
     c->slab_ws = ws;
     if (rows_per_wave) c->slab_rw = rows_per_wave;
+    return SMM_OK;
+}
+extern "C" int smm_ctx_tune_narrow(smm_ctx *c, int enable)
+{
+    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CTX_LOCK(c);
+    c->narrow_idx = enable != 0;
     return SMM_OK;
 }
 extern "C" int smm_ctx_tune_shared(smm_ctx *c, int lds_cols, int waves)
@@ -438,6 +447,7 @@ struct smm_csr {
     std::vector<SegCache> segs;
     std::vector<LocCache> locs;
     std::vector<SlabCache> slabs;
+    unsigned short *idx16 = nullptr;             // 16-bit copy of idx (cols < 65535): the symbolic phase's gather stream
     // sliced-ELL copy for triple-product stage 2 (chunk width ell_chunk)
     int ell_chunk = 0, ell_nchunks = 0; int *ell_len = nullptr; int64_t *ell_off = nullptr;
     short *ell_col = nullptr; double *ell_val = nullptr;
@@ -528,6 +538,7 @@ extern "C" void smm_csr_destroy(smm_csr *m)
     for (auto &e : m->segs) (void)hipFree(e.seg);
     for (auto &e : m->locs) (void)hipFree(e.loc);
     for (auto &e : m->slabs) { (void)hipFree(e.soff); (void)hipFree(e.scol); (void)hipFree(e.sval); }
+    (void)hipFree(m->idx16);
     (void)hipFree(m->ell_len); (void)hipFree(m->ell_off); (void)hipFree(m->ell_col); (void)hipFree(m->ell_val);
     delete m;
 }
@@ -592,6 +603,20 @@ static int ensure_seg(smm_ctx *c, smm_csr *b, const Geom &g, const int **out)
     }
     b->segs.push_back({g.wf, g.n_ft, seg});
     *out = seg;
+    return SMM_OK;
+}
+
+static int ensure_idx16(smm_ctx *c, smm_csr *b)
+{
+    if (b->idx16) return SMM_OK;
+    if (b->cols >= 65535) return fail(SMM_ERR_INVALID, "16-bit column copy needs < 65535 columns");
+    if (hipMalloc((void **)&b->idx16, std::max<int64_t>(b->nnz, 1) * sizeof(unsigned short)) != hipSuccess)
+        return fail(SMM_ERR_ALLOC, "hipMalloc of the 16-bit column copy failed");
+    if (b->nnz > 0) {
+        LAUNCH(c, "smm_idx16", smm_idx16, std::min<int64_t>((b->nnz + 255) / 256, 65536), 256, 0, (int)b->nnz, b->idx, b->idx16);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { (void)hipFree(b->idx16); b->idx16 = nullptr; return fail(SMM_ERR_HIP, "smm_idx16: %s", hipGetErrorString(e)); }
+    }
     return SMM_OK;
 }
 
@@ -749,7 +774,8 @@ struct smm_plan {
     bool b_sorted = true;
     Geom g{};
     int64_t *d_ub_off = nullptr;   // m+1
-    int *d_tmp = nullptr;          // capacity-strided ordered column lists
+    void *d_tmp = nullptr;         // capacity-strided ordered column lists (int32, or uint16 when list16)
+    bool list16 = false;
     unsigned *d_P = nullptr;       // nnz(A)
     unsigned *d_runs = nullptr;    // nnz(A) x (nct+1)
     const int *seg = nullptr;      // B's tile index and tile-local columns for geometry g (owned by b)
@@ -923,17 +949,28 @@ static bool slab_pays(const smm_ctx *c, const smm_csr *a, const SlabGeom &g, dou
     return slab_bytes < 0.7 * tile_bytes && products > 1e7;
 }
 
+template <bool SYM, bool SAFE, int MARK, int UNROLL, bool I16>
+static int launch_symbolic_w(smm_ctx *c, smm_plan *p, int words, unsigned *gbm, int grid, int wpb, const int *rowlist,
+                             const int *d_nrows, int *d_row_counter);
 template <bool SYM, bool SAFE, int MARK, int UNROLL = 16>
 static int launch_symbolic_t(smm_ctx *c, smm_plan *p, int words, unsigned *gbm, int grid, int wpb, const int *rowlist,
                              const int *d_nrows, int *d_row_counter)
 {
+    return p->list16 ? launch_symbolic_w<SYM, SAFE, MARK, UNROLL, true>(c, p, words, gbm, grid, wpb, rowlist, d_nrows, d_row_counter)
+                     : launch_symbolic_w<SYM, SAFE, MARK, UNROLL, false>(c, p, words, gbm, grid, wpb, rowlist, d_nrows, d_row_counter);
+}
+template <bool SYM, bool SAFE, int MARK, int UNROLL, bool I16>
+static int launch_symbolic_w(smm_ctx *c, smm_plan *p, int words, unsigned *gbm, int grid, int wpb, const int *rowlist,
+                             const int *d_nrows, int *d_row_counter)
+{
     // LDS per wave: bitmap words + the guard word, or the hash slots
     const size_t lds = MARK == MARK_GLOBAL_BITMAP ? 0 : (size_t)(words + (MARK == MARK_LDS_HASH ? 0 : 1)) * wpb * sizeof(unsigned);
-    auto kern = smm_symbolic<SYM, SAFE, MARK, UNROLL>;
+    auto kern = smm_symbolic<SYM, SAFE, MARK, UNROLL, I16>;
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     LAUNCH(c, MARK == MARK_LDS_HASH ? "smm_symbolic_hash" : "smm_symbolic", kern, grid, wpb * 64, lds, (int)p->m, rowlist,
-           d_nrows, p->row_offset, words, p->a->ptr, p->a->idx, p->b->ptr, p->b->idx, p->d_ub_off, p->d_tmp, p->d_P,
+           d_nrows, p->row_offset, words, p->a->ptr, p->a->idx, p->b->ptr,
+           I16 ? (const void *)p->b->idx16 : (const void *)p->b->idx, p->d_ub_off, p->d_tmp, p->d_P,
            p->d_rowcnt, gbm, d_row_counter);
     LAUNCH_CHECK();
     return SMM_OK;
@@ -1006,7 +1043,13 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "row work: %s", hipGetErrorString(e)); }
     }
     pool_free(c, d_prod); pool_free(c, d_ub);
-    PCHK(pool_get(c, (size_t)std::max<int64_t>(total_ub, 1), &p->d_tmp));
+    p->list16 = c->narrow_idx && p->ncols < 65535 && b->cols < 65535;
+    if (p->list16) PCHK(ensure_idx16(c, b));
+    {
+        char *tmp = nullptr;
+        PCHK(pool_get(c, (size_t)std::max<int64_t>(total_ub, 1) * (p->list16 ? 2 : 4), &tmp));
+        p->d_tmp = tmp;
+    }
     PCHK(pool_get(c, (size_t)a->nnz, &p->d_P));
     PCHK(pool_get(c, (size_t)m, &p->d_rowcnt));
     if (hmax1 > 0) {            // rows without products are in no bin: their count stays 0
@@ -1092,8 +1135,12 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         PCHK(pool_get(c, (size_t)a->nnz * (p->g.nct + 1), &p->d_runs));
         const int nd = p->n_bin[2];
         const int rgrid = (int)std::min<int64_t>((nd + 3) / 4, 65536);
-        LAUNCH(c, "smm_runs", smm_runs, rgrid, 256, 0, nd, p->g.nct, p->g.wc, (const int *)(p->d_lists + 2 * m), a->ptr,
-               p->d_ub_off, p->d_rowcnt, p->d_P, p->d_tmp, p->d_runs);
+        if (p->list16)
+            LAUNCH(c, "smm_runs", smm_runs<unsigned short>, rgrid, 256, 0, nd, p->g.nct, p->g.wc, (const int *)(p->d_lists + 2 * m), a->ptr,
+                   p->d_ub_off, p->d_rowcnt, p->d_P, (const unsigned short *)p->d_tmp, p->d_runs);
+        else
+            LAUNCH(c, "smm_runs", smm_runs<int>, rgrid, 256, 0, nd, p->g.nct, p->g.wc, (const int *)(p->d_lists + 2 * m), a->ptr,
+                   p->d_ub_off, p->d_rowcnt, p->d_P, (const int *)p->d_tmp, p->d_runs);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "smm_runs: %s", hipGetErrorString(e)); }
     }
@@ -1122,7 +1169,7 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
         H.a_ptr = p->a->ptr; H.a_idx = p->a->idx; H.a_val = p->a->val;
         H.b_ptr = p->b->ptr; H.b_idx = p->b->idx; H.b_val = p->b->val;
         H.c_ptr = p->d_cptr; H.c_idx = d_c_indices; H.c_val = d_c_data;
-        H.ub_off = p->d_ub_off; H.tmp_idx = p->d_tmp;
+        H.ub_off = p->d_ub_off; H.tmp_idx = p->d_tmp; H.list16 = p->list16 ? 1 : 0;
         H.dummy_idx = (const int *)((const char *)c->d_flags + 64);
         H.dummy_val = (const double *)((const char *)c->d_flags + 128);
         if (p->n_bin[0] > 0) {      // one wave per row, four rows per workgroup (always reference order)
@@ -1155,7 +1202,7 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
         A.a_ptr = p->a->ptr; A.a_idx = p->a->idx; A.a_val = p->a->val;
         A.b_idx = p->b->idx; A.b_val = p->b->val; A.seg = p->seg; A.b_loc = p->loc;
         A.c_ptr = p->d_cptr; A.c_idx = d_c_indices; A.c_val = d_c_data;
-        A.ub_off = p->d_ub_off; A.tmp_idx = p->d_tmp; A.runs = p->d_runs;
+        A.ub_off = p->d_ub_off; A.tmp_idx = p->d_tmp; A.list16 = p->list16 ? 1 : 0; A.runs = p->d_runs;
         if (p->use_slab) {
             // values in column order into a dense scratch (one row per row of the bin), then the emission
             double *scratch = nullptr;
@@ -1173,8 +1220,8 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
         CHK(launch_numeric<OUT_SPARSE>(c, A, sym, p->g.nw, exact));
     } else {
         const int cgrid = (int)std::min<int64_t>(nd, 65536);
-        LAUNCH(c, "smm_copy_lists", smm_copy_lists, cgrid, 256, 0, nd, dense_rows, p->d_ub_off, p->d_cptr, p->d_tmp,
-               d_c_indices);
+        LAUNCH(c, "smm_copy_lists", smm_copy_lists, cgrid, 256, 0, nd, dense_rows, p->d_ub_off, p->d_cptr, (const void *)p->d_tmp,
+               p->list16 ? 1 : 0, d_c_indices);
         LAUNCH_CHECK();
         const int grid = (int)std::min<int64_t>((nd + 3) / 4, (int64_t)c->n_cu * 2);
         int *slot = nullptr;
@@ -1348,7 +1395,7 @@ extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags,
     CHK(pool_get(c, (size_t)nr * K, &T));
     if (q->cols < K) HIPCHK(hipMemsetAsync(T, 0, (size_t)nr * K * sizeof(double), c->stream));
     smm_csr hv = *h;                       // row-range view of H (borrowed arrays)
-    hv.ptr = h->ptr + row_begin; hv.rows = nr; hv.owned = false; hv.segs.clear(); hv.locs.clear(); hv.slabs.clear();
+    hv.ptr = h->ptr + row_begin; hv.rows = nr; hv.owned = false; hv.segs.clear(); hv.locs.clear(); hv.slabs.clear(); hv.idx16 = nullptr;
     // indptr of the view is not rebased: kernels only use ptr[row], ptr[row+1] as absolute positions.
     int rc = dense_into(c, &hv, q, flags & SMM_EXACT, 0, T, K);
     if (rc != SMM_OK) { pool_free(c, T); return rc; }

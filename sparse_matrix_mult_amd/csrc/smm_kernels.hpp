@@ -22,6 +22,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace smm {
 
@@ -108,6 +109,15 @@ __device__ __forceinline__ void wait_vm_pair(int &c, double &v, int n) {
         SMM_W(24) SMM_W(25) SMM_W(26) SMM_W(27) SMM_W(28) SMM_W(29) SMM_W(30) SMM_W(31)
     }
 #undef SMM_W
+}
+// the same for a 16-bit column stream (zero-extended): per-lane offset 2*lane
+__device__ __forceinline__ void load_masked(int &v, const unsigned short *idx, unsigned long long mask, int lane4) {
+    const int lane2 = lane4 >> 1;
+    asm volatile("s_mov_b64 exec, %3\n\t"
+                 "global_load_ushort %0, %1, %2\n\t"
+                 "s_mov_b64 exec, -1"
+                 : "+v"(v)
+                 : "v"(lane2), "s"(idx), "s"(mask));
 }
 // n is a constant after unrolling; the switch folds to one s_waitcnt
 __device__ __forceinline__ void wait_vm(int &v, int n) {
@@ -201,6 +211,19 @@ __global__ __launch_bounds__(256) void smm_loc16(int nnz, int wc, const int *__r
 {
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += gridDim.x * blockDim.x)
         loc[k] = (short)(idx[k] % wc);
+}
+
+// 16-bit copy of an operand's column indices (operands with < 65 535 columns): the symbolic phase gathers
+// these 2 bytes per product instead of 4 -- half of its fabric traffic.
+__global__ __launch_bounds__(256) void smm_idx16(int nnz, const int *__restrict__ idx, unsigned short *__restrict__ out)
+{
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += gridDim.x * blockDim.x) out[k] = (unsigned short)idx[k];
+}
+
+// The ordered lists of smm_symbolic hold int32 columns, or uint16 when B has < 65 535 columns (l16): they are
+// written once and read twice (smm_runs, the numeric epilogue) -- 10 GB each way at 50k x 50k as int32.
+__device__ __forceinline__ int list_at(const void *list, int64_t i, bool l16) {
+    return l16 ? (int)((const unsigned short *)list)[i] : ((const int *)list)[i];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -337,21 +360,25 @@ __global__ __launch_bounds__(1024) void smm_scan_tiles(int n, const T *__restric
 // SYM_UNROLL = chunk loads in flight per wave: 16 when many waves fit a CU (8 and 32 measured slower at
 // 50 000 columns, 24 waves); 32 when the bitmap leaves few waves per CU and a round is pure latency.
 enum { MARK_LDS_BITMAP = 0, MARK_GLOBAL_BITMAP = 1, MARK_LDS_HASH = 2 };
-template <bool SYM, bool SAFE, int MARK, int SYM_UNROLL>
+// I16: B's columns are read from the 16-bit copy (smm_idx16) and the lists are written as uint16.
+template <bool SYM, bool SAFE, int MARK, int SYM_UNROLL, bool I16 = false>
 __global__ __launch_bounds__(256) void smm_symbolic(int m, const int *__restrict__ rowlist,
                                                     const int *__restrict__ nrows_p, int64_t row_offset, int bm_words,
                                                     const int *__restrict__ a_ptr,
                                                     const int *__restrict__ a_idx,
                                                     const int *__restrict__ b_ptr,
-                                                    const int *__restrict__ b_idx,
+                                                    const void *__restrict__ b_idx_v,
                                                     const int64_t *__restrict__ ub_off,
-                                                    int *__restrict__ tmp_idx,
+                                                    void *__restrict__ tmp_idx_v,
                                                     unsigned *__restrict__ P,
                                                     int *__restrict__ rowcnt,
                                                     unsigned *__restrict__ gbitmap,
                                                     int *__restrict__ row_counter)
 {
     extern __shared__ unsigned lds_bm[];
+    using IT = std::conditional_t<I16, unsigned short, int>;
+    const IT *__restrict__ b_idx = (const IT *)b_idx_v;
+    IT *__restrict__ tmp_idx = (IT *)tmp_idx_v;
     constexpr bool HASH = MARK == MARK_LDS_HASH;
     static_assert(!(HASH && SAFE), "rows of B with repeated columns take the bitmap kernels");
     const int lane = lane_id();
@@ -391,7 +418,7 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, const int *__restrict
         const int a0 = a_ptr[row], a1 = a_ptr[row + 1];
         int thresh = 0;
         if (SYM) { const int64_t gi = row + row_offset; thresh = gi > 0x7fffffff ? 0x7fffffff : (int)gi; }
-        int *__restrict__ out = tmp_idx + ub_off[row];
+        IT *__restrict__ out = tmp_idx + ub_off[row];
         int n = 0;
         if (a1 > a0) {
             auto load_r = [&](int jb) { int e = jb + lane; e = e < a1 ? e : a1 - 1; return a_idx[e]; };
@@ -466,7 +493,7 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, const int *__restrict
                                 const unsigned long long mask = __ballot(isnew);
                                 if (isnew)
                                     out[__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                  __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)n))] = c[u];
+                                                                  __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)n))] = (IT)c[u];
                                 n += __popcll(mask);
                             }
                         } else {
@@ -506,7 +533,7 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, const int *__restrict
                             const unsigned long long mask = __ballot(isnew);
                             if (isnew)
                                 out[__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                              __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)n))] = c[u];
+                                                              __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)n))] = (IT)c[u];
                             n += __popcll(mask);
                         }
                         }
@@ -555,12 +582,13 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, const int *__restrict
 // next window is already on its way while one is searched), and the lanes search there (a first version searched in global memory: ~70 dependent probes per lane into
 // lines nobody else used, 19 ms at 200 000 columns / 10 tiles; this one streams the list once).
 constexpr int RUNS_WIN = 2048;
+template <typename LT>
 __global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc, const int *__restrict__ rowlist,
                                                 const int *__restrict__ a_ptr,
                                                 const int64_t *__restrict__ ub_off,
                                                 const int *__restrict__ rowcnt,
                                                 const unsigned *__restrict__ P,
-                                                const int *__restrict__ tmp_idx,
+                                                const LT *__restrict__ tmp_idx,
                                                 unsigned *__restrict__ runs)
 {
     __shared__ int win_all[4][RUNS_WIN];
@@ -571,7 +599,7 @@ __global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc, const in
     for (int ri = blockIdx.x * wpb + (threadIdx.x >> 6); ri < m; ri += gridDim.x * wpb) {
         const int row = rowlist ? rowlist[ri] : ri;
         const int a0 = a_ptr[row], a1 = a_ptr[row + 1];
-        const int *__restrict__ list = tmp_idx + ub_off[row];
+        const LT *__restrict__ list = tmp_idx + ub_off[row];
         const unsigned total = (unsigned)rowcnt[row];
         // The row's list is cut into fixed windows of RUNS_WIN entries.  Window k sits in LDS while
         // window k+1 travels in registers (its loads are issued before the searches in window k).
@@ -580,7 +608,7 @@ __global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc, const in
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 const unsigned i = wb + u * WAVE + lane;
-                v[u] = list[i < total ? i : (total ? total - 1 : 0)];
+                v[u] = (int)list[i < total ? i : (total ? total - 1 : 0)];
             }
         };
         unsigned cur = 0xffffffffu;                 // start of the window that is in LDS
@@ -661,7 +689,8 @@ struct NumericArgs {
     const double *dummy_val;        // one double
     // sparse output
     const int64_t *c_ptr; int *c_idx; double *c_val;
-    const int64_t *ub_off; const int *tmp_idx;   // ordered column lists of smm_symbolic
+    const int64_t *ub_off; const void *tmp_idx;  // ordered column lists of smm_symbolic (int32, or uint16 when list16)
+    int list16;
     const unsigned *runs;           // [nnzA][nct+1] sub-run table (smm_runs)
     const int *rowlist;             // rows handled by this launch (NULL = all m rows)
     unsigned long long *stamps;     // diagnostic builds (-DSMM_STAMPS) only: 4 phase totals
@@ -947,7 +976,8 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
         // scan, issues EPI_UNROLL chunk loads at a time and then stores.  The whole epilogue of a
         // unit costs a handful of memory round trips (an earlier version walked the entries 64 at a
         // time, one dependent round trip per batch and per long sub-run, and took 37 % of the kernel).
-        const int *__restrict__ list = A.tmp_idx + A.ub_off[row];
+        const bool l16 = A.list16 != 0;
+        const char *__restrict__ list = (const char *)A.tmp_idx + (A.ub_off[row] << (l16 ? 1 : 2));
         int *__restrict__ oi = A.c_idx + rs;
         double *__restrict__ ov = A.c_val + rs;
         const size_t per = (size_t)A.nct + 1;
@@ -977,8 +1007,14 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
                     const unsigned s0 = rl(r0, i), s1 = rl(r1, i);
                     sl[u] = s0 + ((unsigned)(t - first) << 6) + (unsigned)lane;
                     const bool p = t < total && sl[u] < s1;
-                    const int *ip = p ? list + sl[u] : A.dummy_idx;
-                    c[u] = ld_stream(ip);
+                    if (l16) {      // 0xffff (the dummy word read by idle lanes) is no column: B has < 65 535 of them
+                        const unsigned short *ip = p ? (const unsigned short *)list + sl[u] : (const unsigned short *)A.dummy_idx;
+                        const int x = (int)ld_stream(ip);
+                        c[u] = x == 0xffff ? -1 : x;
+                    } else {
+                        const int *ip = p ? (const int *)list + sl[u] : A.dummy_idx;
+                        c[u] = ld_stream(ip);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < EPI_UNROLL; ++u)
@@ -1047,7 +1083,7 @@ struct HashArgs {
     const int *a_ptr, *a_idx; const double *a_val;
     const int *b_ptr, *b_idx; const double *b_val;
     const int64_t *c_ptr; int *c_idx; double *c_val;
-    const int64_t *ub_off; const int *tmp_idx;
+    const int64_t *ub_off; const void *tmp_idx; int list16;
     const int *dummy_idx; const double *dummy_val;
 };
 
@@ -1078,14 +1114,15 @@ __global__ __launch_bounds__(NW * TPB * 64) void smm_numeric_hash(const HashArgs
         const int row = have ? A.rowlist[ri] : 0;
         const int64_t rs = have ? A.c_ptr[row] : 0;
         const int cnt = have ? (int)(A.c_ptr[row + 1] - rs) : 0;
-        const int *__restrict__ list = A.tmp_idx + (have ? A.ub_off[row] : 0);
+        const bool l16 = A.list16 != 0;
+        const int64_t lbase = have ? A.ub_off[row] : 0;
         // 1. empty table, accumulators at -0.0 (additive identity: reproduces `values[i] = p`)
         for (int h = tlane; h < HSIZE; h += TN) keys[h] = -1;
         for (int s = tlane; s < cnt; s += TN) vals[s] = -0.0;
         team_sync();
         // 2. insert the row's columns: slot = position in the first-touch list
         for (int s = tlane; s < cnt; s += TN) {
-            const int c = list[s];
+            const int c = list_at(A.tmp_idx, lbase + s, l16);
             int h = hash(c);
             while (atomicCAS(&keys[h], -1, c) != -1) h = (h + 1) & (HSIZE - 1);
             slots[h] = (unsigned short)s;
@@ -1158,7 +1195,7 @@ __global__ __launch_bounds__(NW * TPB * 64) void smm_numeric_hash(const HashArgs
         team_sync();
         // 4. the row, in first-touch order
         for (int s = tlane; s < cnt; s += TN) {
-            A.c_idx[rs + s] = list[s];
+            A.c_idx[rs + s] = list_at(A.tmp_idx, lbase + s, l16);
             A.c_val[rs + s] = vals[s];
         }
         team_sync();
@@ -1171,14 +1208,14 @@ __global__ __launch_bounds__(NW * TPB * 64) void smm_numeric_hash(const HashArgs
 __global__ __launch_bounds__(256) void smm_copy_lists(int m, const int *__restrict__ rowlist,
                                                       const int64_t *__restrict__ ub_off,
                                                       const int64_t *__restrict__ c_ptr,
-                                                      const int *__restrict__ tmp_idx,
+                                                      const void *__restrict__ tmp_idx, int list16,
                                                       int *__restrict__ c_idx)
 {
     for (int ri = blockIdx.x; ri < m; ri += gridDim.x) {
         const int row = rowlist ? rowlist[ri] : ri;
         const int64_t src = ub_off[row], dst = c_ptr[row];
         const int n = (int)(c_ptr[row + 1] - dst);
-        for (int s = threadIdx.x; s < n; s += blockDim.x) c_idx[dst + s] = tmp_idx[src + s];
+        for (int s = threadIdx.x; s < n; s += blockDim.x) c_idx[dst + s] = list_at(tmp_idx, src + s, list16 != 0);
     }
 }
 

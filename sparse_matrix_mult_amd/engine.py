@@ -77,6 +77,10 @@ class Context:
         rows_per_wave 2 or 4."""
         check(self.lib, self.lib.smm_ctx_tune_slab(self.handle, int(mode), int(ws), int(rows_per_wave)))
 
+    def tune_narrow(self, enable=True):
+        """uint16 column stream / lists in the symbolic phase for operands with < 65535 columns (default on)."""
+        check(self.lib, self.lib.smm_ctx_tune_narrow(self.handle, 1 if enable else 0))
+
     def timing(self, enable=True):
         check(self.lib, self.lib.smm_ctx_timing(self.handle, 1 if enable else 0))
 

@@ -13,20 +13,24 @@ from helpers import arrays, assert_csr_equal, rel_err
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["hash+tiles", "tiles-only", "small-hash", "slab-all", "slab-narrow"], autouse=True)
+@pytest.fixture(params=["hash+tiles", "tiles-only", "small-hash", "slab-all", "slab-narrow", "idx32"], autouse=True)
 def numeric_paths(request, ctx):
     """Every case runs with the default dispatch (rows with few nonzeros -> LDS hash kernels, the
     rest -> dense LDS tiles), with the hash kernels off, with only the one-wave hash kernel
     on and a low threshold (mixes all three kernels inside one product), and with the row-block x
-    column-slab kernels forced (L2-sized slabs for every row; 50-column slabs next to the hash kernels)."""
+    column-slab kernels forced (L2-sized slabs for every row; 50-column slabs next to the hash kernels); "idx32"
+    switches the 16-bit column stream / lists of the symbolic phase off (every other configuration has them on
+    wherever B has < 65535 columns)."""
     hash_cfg, slab_cfg = {"hash+tiles": ((256, 2048), (0, 0, 4)), "tiles-only": ((0, 0), (0, 0, 4)),
                           "small-hash": ((24, 150), (0, 0, 4)), "slab-all": ((0, 0), (2, 0, 4)),
-                          "slab-narrow": ((24, 150), (2, 50, 2))}[request.param]
+                          "slab-narrow": ((24, 150), (2, 50, 2)), "idx32": ((24, 150), (0, 0, 4))}[request.param]
     ctx.tune_hash(*hash_cfg)
     ctx.tune_slab(*slab_cfg)
+    ctx.tune_narrow(request.param != "idx32")
     yield
     ctx.tune_hash(256, 2048)
     ctx.tune_slab(0, 0, 4)
+    ctx.tune_narrow(True)
 RTOL = 1e-10
 
 
