@@ -713,12 +713,15 @@ extern "C" int smm_row_products(smm_ctx *c, const smm_csr *a, const smm_csr *b, 
 }
 
 // ------------------------------------------------------------------------------ numeric dispatch
-template <int OUT, bool SYM, int NW, bool EXACT, bool SCR = false>
+template <int OUT, bool SYM, int NW, bool EXACT, bool SCR = false, bool L16 = false>
 static int launch_numeric_t(smm_ctx *c, NumericArgs &args)
 {
+    if constexpr (OUT == OUT_SPARSE && !L16) {
+        if (args.list16) return launch_numeric_t<OUT, SYM, NW, EXACT, SCR, true>(c, args);
+    }
     // accumulator tile (+ the exact walk's per-wave scratch behind it)
     const size_t lds = (size_t)((args.wc + 1) & ~1) * sizeof(double) + (EXACT ? (size_t)NW * sizeof(ExactScratch) : 0);
-    auto kern = smm_numeric<OUT, SYM, NW, EXACT, SCR>;
+    auto kern = smm_numeric<OUT, SYM, NW, EXACT, SCR, L16>;
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t grid = (int64_t)args.m * args.nct;

@@ -909,7 +909,9 @@ constexpr int EPI_UNROLL = SMM_EPI_UNROLL;
 // SCR: the tile is not accumulated here but loaded from the dense scratch rows smm_dense_slab left
 // in column order (A.c_dense / A.ldc, one scratch row per row of the launch); the kernel is then only
 // the first-touch emission.
-template <int OUT, bool SYM, int NW, bool EXACT, bool SCR = false>
+// L16: the ordered lists are uint16 (a template parameter, not a run-time switch: a branch inside the epilogue's
+// "all loads first" loop made every load wait for the one before it -- 30 -> 37 ms).
+template <int OUT, bool SYM, int NW, bool EXACT, bool SCR = false, bool L16 = false>
 __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
 {
     static_assert(!SCR || OUT == OUT_SPARSE, "the scratch source feeds the CSR emission only");
@@ -976,8 +978,8 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
         // scan, issues EPI_UNROLL chunk loads at a time and then stores.  The whole epilogue of a
         // unit costs a handful of memory round trips (an earlier version walked the entries 64 at a
         // time, one dependent round trip per batch and per long sub-run, and took 37 % of the kernel).
-        const bool l16 = A.list16 != 0;
-        const char *__restrict__ list = (const char *)A.tmp_idx + (A.ub_off[row] << (l16 ? 1 : 2));
+        using LT = std::conditional_t<L16, unsigned short, int>;
+        const LT *__restrict__ list = (const LT *)A.tmp_idx + A.ub_off[row];
         int *__restrict__ oi = A.c_idx + rs;
         double *__restrict__ ov = A.c_val + rs;
         const size_t per = (size_t)A.nct + 1;
@@ -1007,18 +1009,12 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
                     const unsigned s0 = rl(r0, i), s1 = rl(r1, i);
                     sl[u] = s0 + ((unsigned)(t - first) << 6) + (unsigned)lane;
                     const bool p = t < total && sl[u] < s1;
-                    if (l16) {      // 0xffff (the dummy word read by idle lanes) is no column: B has < 65 535 of them
-                        const unsigned short *ip = p ? (const unsigned short *)list + sl[u] : (const unsigned short *)A.dummy_idx;
-                        const int x = (int)ld_stream(ip);
-                        c[u] = x == 0xffff ? -1 : x;
-                    } else {
-                        const int *ip = p ? (const int *)list + sl[u] : A.dummy_idx;
-                        c[u] = ld_stream(ip);
-                    }
+                    const LT *ip = p ? list + sl[u] : (const LT *)A.dummy_idx;
+                    c[u] = (int)ld_stream(ip);
                 }
 #pragma unroll
-                for (int u = 0; u < EPI_UNROLL; ++u)
-                    if (c[u] >= 0) { st_stream(&oi[sl[u]], c[u]); st_stream(&ov[sl[u]], acc[c[u] - lo_c]); }
+                for (int u = 0; u < EPI_UNROLL; ++u)        // idle lanes read the dummy word: -1, or 0xffff as uint16 (no column: B has < 65 535)
+                    if (L16 ? c[u] != 0xffff : c[u] >= 0) { st_stream(&oi[sl[u]], c[u]); st_stream(&ov[sl[u]], acc[c[u] - lo_c]); }
             }
         }
     }
