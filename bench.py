@@ -242,7 +242,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-    ktimes = {k: ctx.kernel_time(k) for k in NUMERIC_KERNELS + ("smm_numeric_dense", "smm_symbolic", "smm_runs", "smm_triple_stage2")}
+    ktimes = {k: ctx.kernel_time(k) for k in NUMERIC_KERNELS + ("smm_numeric_dense", "smm_numeric_hash", "smm_symbolic", "smm_symbolic_hash",
+                                                                 "smm_runs", "smm_triple_stage2")}
     ctx.timing(False)
 
     t = torch.tensor([elapsed, float(units)], dtype=torch.float64, device="cpu" if rehearsal else device)
