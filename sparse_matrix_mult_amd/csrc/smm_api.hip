@@ -446,7 +446,9 @@ struct smm_csr {
     struct SlabCache { int ws, n_slabs; int *soff; short *scol; double *sval; };   // slab-major copy (smm_slab.hpp)
     std::vector<SegCache> segs;
     std::vector<LocCache> locs;
+    struct PackCache { int wc, nct; int2 *desc; double *pay; };   // packed tile-major payload (smm_pack_*)
     std::vector<SlabCache> slabs;
+    std::vector<PackCache> packs;
     unsigned short *idx16 = nullptr;             // 16-bit copy of idx (cols < 65535): the symbolic phase's gather stream
     // sliced-ELL copy for triple-product stage 2 (chunk width ell_chunk)
     int ell_chunk = 0, ell_nchunks = 0; int *ell_len = nullptr; int64_t *ell_off = nullptr;
@@ -538,6 +540,7 @@ extern "C" void smm_csr_destroy(smm_csr *m)
     for (auto &e : m->segs) (void)hipFree(e.seg);
     for (auto &e : m->locs) (void)hipFree(e.loc);
     for (auto &e : m->slabs) { (void)hipFree(e.soff); (void)hipFree(e.scol); (void)hipFree(e.sval); }
+    for (auto &e : m->packs) { (void)hipFree(e.desc); (void)hipFree(e.pay); }
     (void)hipFree(m->idx16);
     (void)hipFree(m->ell_len); (void)hipFree(m->ell_off); (void)hipFree(m->ell_col); (void)hipFree(m->ell_val);
     delete m;
@@ -783,9 +786,10 @@ struct smm_plan {
     unsigned *d_runs = nullptr;    // nnz(A) x (nct+1)
     const int *seg = nullptr;      // B's tile index and tile-local columns for geometry g (owned by b)
     const short *loc = nullptr;
+    smm_csr::PackCache pack{0, 0, nullptr, nullptr};   // default mode: packed payload of B for geometry g
     bool use_slab = false;         // dense-bin rows: smm_dense_slab -> scratch -> emission, instead of the tile kernel
     SlabGeom sg{};
-    const smm_csr::SlabCache *slab = nullptr;
+    smm_csr::SlabCache slab{0, 0, nullptr, nullptr, nullptr};
     int *d_rowcnt = nullptr;       // m
     int *d_lists = nullptr;        // 3 x m: rows of the small / medium / dense bins
     int n_bin[3] = {0, 0, 0};
@@ -826,6 +830,53 @@ static int scan_launch(smm_ctx *c, int64_t n, const T *in, int64_t *out)
     return SMM_OK;
 }
 
+// Packed tile-major payload of B for the shared-tile walk (smm_pack_* in smm_kernels.hpp), cached per geometry.
+// (descriptors are handed out BY VALUE: a plan must not point into the operand's vector, which may grow)
+static int ensure_pack(smm_ctx *c, smm_csr *b, const Geom &g, smm_csr::PackCache *out)
+{
+    for (auto &e : b->packs)
+        if (e.wc == g.wc && e.nct == g.nct) { *out = e; return SMM_OK; }
+    if (g.wc > 32767) return fail(SMM_ERR_INVALID, "coarse tile wider than 32767 columns");
+    Geom gs = g; gs.wf = g.wc; gs.n_ft = g.nct;               // the coarse-tile index (shared walk: one entry per coarse tile)
+    const int *seg = nullptr;
+    CHK(ensure_seg(c, b, gs, &seg));
+    const int64_t cells = (int64_t)g.nct * b->rows;
+    if (cells + 1 >= INT32_MAX) return fail(SMM_ERR_INVALID, "too many (tile, row) pieces");
+    int *units = nullptr; int64_t *off64 = nullptr;
+    CHK(pool_get(c, (size_t)std::max<int64_t>(cells, 1), &units));
+    int rc = pool_get(c, (size_t)cells + 1, &off64);
+    if (rc != SMM_OK) { pool_free(c, units); return rc; }
+    if (cells > 0) LAUNCH(c, "smm_pack_count", smm_pack_count, (cells + 255) / 256, 256, 0, (int)b->rows, g.nct, seg, units);
+    rc = scan_launch<int>(c, cells, units, off64);
+    int64_t total = 0;
+    if (rc == SMM_OK) {
+        hipError_t e = hipMemcpyAsync(&total, off64 + cells, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(SMM_ERR_HIP, "pack build: %s", hipGetErrorString(e));
+    }
+    if (rc == SMM_OK && total >= INT32_MAX) rc = fail(SMM_ERR_INVALID, "operand too large for the packed payload");
+    smm_csr::PackCache e{g.wc, g.nct, nullptr, nullptr};
+    if (rc == SMM_OK &&
+        (hipMalloc((void **)&e.desc, (size_t)std::max<int64_t>(cells, 1) * sizeof(int2)) != hipSuccess ||
+         hipMalloc((void **)&e.pay, (size_t)std::max<int64_t>(total, 1) * sizeof(double)) != hipSuccess)) {
+        (void)hipFree(e.desc); (void)hipFree(e.pay);
+        rc = fail(SMM_ERR_ALLOC, "hipMalloc of the packed payload failed");
+    }
+    if (rc == SMM_OK && cells > 0) {
+        LAUNCH(c, "smm_pack_desc", smm_pack_desc, (cells + 255) / 256, 256, 0, (int)b->rows, g.nct, seg, (const int64_t *)off64, e.desc);
+        LAUNCH(c, "smm_pack_fill", smm_pack_fill, std::min<int64_t>((b->rows + 3) / 4, 65536), 256, 0, (int)b->rows, g.nct, g.wc, b->ptr,
+               b->idx, b->val, seg, (const int2 *)e.desc, e.pay);
+        hipError_t he = hipGetLastError();
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);        // units / off64 go back to the pool
+        if (he != hipSuccess) { (void)hipFree(e.desc); (void)hipFree(e.pay); rc = fail(SMM_ERR_HIP, "pack build: %s", hipGetErrorString(he)); }
+    }
+    pool_free(c, units); pool_free(c, off64);
+    if (rc != SMM_OK) return rc;
+    b->packs.push_back(e);
+    *out = e;
+    return SMM_OK;
+}
+
 // ------------------------------------------------------------------------------ row block x column slab path
 
 // Slab width: the slab's share of B's payload (10 bytes per entry) should sit in one XCD's 4 MiB L2 next
@@ -857,10 +908,10 @@ static bool slab_geometry(const smm_ctx *c, const smm_csr *b, int64_t ncols, Sla
     return true;
 }
 
-static int ensure_slab(smm_ctx *c, smm_csr *b, const SlabGeom &g, const smm_csr::SlabCache **out)
+static int ensure_slab(smm_ctx *c, smm_csr *b, const SlabGeom &g, smm_csr::SlabCache *out)
 {
     for (auto &e : b->slabs)
-        if (e.ws == g.ws && e.n_slabs == g.n_slabs) { *out = &e; return SMM_OK; }
+        if (e.ws == g.ws && e.n_slabs == g.n_slabs) { *out = e; return SMM_OK; }
     Geom gs; gs.nw = 1; gs.nct = g.n_slabs; gs.wc = g.ws; gs.wf = g.ws; gs.n_ft = g.n_slabs;
     const int *seg = nullptr;
     CHK(ensure_seg(c, b, gs, &seg));
@@ -891,7 +942,7 @@ static int ensure_slab(smm_ctx *c, smm_csr *b, const SlabGeom &g, const smm_csr:
     pool_free(c, cnt); pool_free(c, off64);
     if (rc != SMM_OK) { (void)hipFree(e.soff); (void)hipFree(e.scol); (void)hipFree(e.sval); return rc; }
     b->slabs.push_back(e);
-    *out = &b->slabs.back();
+    *out = e;
     return SMM_OK;
 }
 
@@ -1131,9 +1182,11 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
                       slab_pays(c, a, p->sg, (double)p->n_bin[2] * (double)p->ncols, est_products, (double)p->nnz,
                                 (double)b->nnz / (double)std::max<int64_t>(b->rows, 1), (double)p->ncols);
         if (p->use_slab) PCHK(ensure_slab(c, b, p->sg, &p->slab));
-        else {
+        else if (flags & SMM_EXACT) {
             PCHK(ensure_seg(c, b, p->g, &p->seg));
             PCHK(ensure_loc(c, b, p->g, &p->loc));
+        } else {
+            PCHK(ensure_pack(c, b, p->g, &p->pack));
         }
         PCHK(pool_get(c, (size_t)a->nnz * (p->g.nct + 1), &p->d_runs));
         const int nd = p->n_bin[2];
@@ -1204,13 +1257,15 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
         A.rowlist = dense_rows;
         A.a_ptr = p->a->ptr; A.a_idx = p->a->idx; A.a_val = p->a->val;
         A.b_idx = p->b->idx; A.b_val = p->b->val; A.seg = p->seg; A.b_loc = p->loc;
+        A.tdesc = p->pack.desc; A.tpay = p->pack.pay;
+        A.rowsB = (int)p->b->rows;
         A.c_ptr = p->d_cptr; A.c_idx = d_c_indices; A.c_val = d_c_data;
         A.ub_off = p->d_ub_off; A.tmp_idx = p->d_tmp; A.list16 = p->list16 ? 1 : 0; A.runs = p->d_runs;
         if (p->use_slab) {
             // values in column order into a dense scratch (one row per row of the bin), then the emission
             double *scratch = nullptr;
             CHK(pool_get(c, (size_t)nd * (size_t)p->ncols, &scratch));
-            int rc = launch_slab<true>(c, p->a, p->b, *p->slab, p->sg.rw, nd, dense_rows, sym, p->row_offset, scratch, p->ncols);
+            int rc = launch_slab<true>(c, p->a, p->b, p->slab, p->sg.rw, nd, dense_rows, sym, p->row_offset, scratch, p->ncols);
             if (rc == SMM_OK) {
                 A.c_dense = scratch; A.ldc = p->ncols;
                 A.dummy_idx = (const int *)((const char *)c->d_flags + 64);
@@ -1297,20 +1352,27 @@ static int dense_into(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t row
     if (slab_geometry(c, b, n, &sg) &&
         slab_pays(c, a, sg, (double)m * (double)n, (double)a->nnz * ((double)b->nnz / (double)std::max<int64_t>(b->rows, 1)), -1.0,
                   (double)b->nnz / (double)std::max<int64_t>(b->rows, 1), (double)n)) {
-        const smm_csr::SlabCache *sl = nullptr;
+        smm_csr::SlabCache sl{0, 0, nullptr, nullptr, nullptr};
         CHK(ensure_slab(c, b, sg, &sl));
-        return launch_slab<false>(c, a, b, *sl, sg.rw, (int)m, nullptr, sym, row_offset, d_c, ldc);
+        return launch_slab<false>(c, a, b, sl, sg.rw, (int)m, nullptr, sym, row_offset, d_c, ldc);
     }
     if (!(b->vflags & CSR_UNSORTED)) {
         Geom g = make_geom(c, n, b, (flags & SMM_EXACT) != 0);
         const int *seg = nullptr; const short *loc = nullptr;
-        CHK(ensure_seg(c, b, g, &seg));
-        CHK(ensure_loc(c, b, g, &loc));
+        smm_csr::PackCache pack{0, 0, nullptr, nullptr};
+        if (flags & SMM_EXACT) {
+            CHK(ensure_seg(c, b, g, &seg));
+            CHK(ensure_loc(c, b, g, &loc));
+        } else {
+            CHK(ensure_pack(c, b, g, &pack));
+        }
         NumericArgs A{};
         A.m = (int)m; A.ncols = (int)n; A.nct = g.nct; A.wc = g.wc; A.wf = g.wf; A.n_ft = g.n_ft;
         A.row_offset = row_offset;
         A.a_ptr = a->ptr; A.a_idx = a->idx; A.a_val = a->val;
         A.b_idx = b->idx; A.b_val = b->val; A.seg = seg; A.b_loc = loc;
+        A.tdesc = pack.desc; A.tpay = pack.pay;
+        A.rowsB = (int)b->rows;
         A.c_dense = d_c; A.ldc = ldc;
         CHK(launch_numeric<OUT_DENSE>(c, A, sym, g.nw, (flags & SMM_EXACT) != 0));
     } else {
@@ -1398,7 +1460,7 @@ extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags,
     CHK(pool_get(c, (size_t)nr * K, &T));
     if (q->cols < K) HIPCHK(hipMemsetAsync(T, 0, (size_t)nr * K * sizeof(double), c->stream));
     smm_csr hv = *h;                       // row-range view of H (borrowed arrays)
-    hv.ptr = h->ptr + row_begin; hv.rows = nr; hv.owned = false; hv.segs.clear(); hv.locs.clear(); hv.slabs.clear(); hv.idx16 = nullptr;
+    hv.ptr = h->ptr + row_begin; hv.rows = nr; hv.owned = false; hv.segs.clear(); hv.locs.clear(); hv.slabs.clear(); hv.packs.clear(); hv.idx16 = nullptr;
     // indptr of the view is not rebased: kernels only use ptr[row], ptr[row+1] as absolute positions.
     int rc = dense_into(c, &hv, q, flags & SMM_EXACT, 0, T, K);
     if (rc != SMM_OK) { pool_free(c, T); return rc; }
