@@ -479,12 +479,7 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, const int *__restrict
                 asm volatile("" : "+v"(bs), "+v"(be));
                 // entry `lane` of the batch owns the chunks [excl, incl) of the batch's chunk list
                 const int nch = lane < nb ? (be - bs + WAVE - 1) >> 6 : 0;
-                int incl = nch;
-#pragma unroll
-                for (int o = 1; o < WAVE; o <<= 1) {
-                    const int y = __shfl_up(incl, o);
-                    if (lane >= o) incl += y;
-                }
+                const int incl = wave_scan_incl(nch);
                 const int excl = incl - nch;
                 const int T = rl(incl, WAVE - 1);
                 for (int tg = 0; tg < T; tg += WAVE) {
@@ -802,12 +797,7 @@ __device__ __forceinline__ void smm_accumulate(const NumericArgs &A, double *__r
         load_a(jb + 2 * WAVE, r_nn, a_nn);             // A entries two batches ahead
         // stream of this batch: entry j owns positions [first_j, first_j + len_j)
         const int len = lane < nb ? e_c - s_c : 0;
-        int incl = len;
-#pragma unroll
-        for (int o = 1; o < WAVE; o <<= 1) {
-            const int y = __shfl_up(incl, o);
-            if (lane >= o) incl += y;
-        }
+        const int incl = wave_scan_incl(len);
         const int first = incl - len;
         const int total = rl(incl, WAVE - 1);
         sc->tab[lane] = make_int4(s_c - first, 0, __double2loint(a_c), __double2hiint(a_c));
@@ -1027,12 +1017,7 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
             const unsigned r0 = rp[0];
             const unsigned r1 = ev ? rp[1] : r0;
             const int nch = (int)((r1 - r0 + WAVE - 1) >> 6);
-            int incl = nch;
-#pragma unroll
-            for (int o = 1; o < WAVE; o <<= 1) {
-                const int y = __shfl_up(incl, o);
-                if (lane >= o) incl += y;
-            }
+            const int incl = wave_scan_incl(nch);
             const int total = rl(incl, WAVE - 1);
             for (int t0 = 0; t0 < total; t0 += EPI_UNROLL) {
                 int c[EPI_UNROLL];
