@@ -855,7 +855,7 @@ __device__ __forceinline__ void smm_accumulate(const NumericArgs &A, double *__r
 // kernel slower, 29.5 -> 30.6 ms: it is bound by the gather, not by instruction issue, and the scalar
 // address arithmetic between the loads spreads their issue out.)
 #ifndef SMM_CH_UNROLL
-#define SMM_CH_UNROLL 16
+#define SMM_CH_UNROLL 8
 #endif
 constexpr int CH_UNROLL = SMM_CH_UNROLL;
 
@@ -910,7 +910,7 @@ __device__ __forceinline__ void smm_accumulate_shared(const NumericArgs &A, doub
 }
 
 #ifndef SMM_EPI_UNROLL
-#define SMM_EPI_UNROLL 16
+#define SMM_EPI_UNROLL 8
 #endif
 // Streams that are touched once (the result, the ordered lists) carry the non-temporal hint so that they
 // do not push B -- re-read by every row -- out of the Infinity Cache.  -DSMM_NT=0 builds without it.
