@@ -784,6 +784,7 @@ struct smm_plan {
     bool list16 = false;
     unsigned *d_P = nullptr;       // nnz(A)
     unsigned *d_runs = nullptr;    // nnz(A) x (nct+1)
+    int2 *d_tail = nullptr;        // m: where the tail of every row starts (smm_runs)
     const int *seg = nullptr;      // B's tile index and tile-local columns for geometry g (owned by b)
     const short *loc = nullptr;
     smm_csr::PackCache pack{0, 0, nullptr, nullptr};   // default mode: packed payload of B for geometry g
@@ -804,7 +805,7 @@ extern "C" void smm_plan_destroy(smm_plan *p)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     pool_free(c, p->d_ub_off); pool_free(c, p->d_tmp); pool_free(c, p->d_P); pool_free(c, p->d_runs);
-    pool_free(c, p->d_rowcnt); pool_free(c, p->d_cptr); pool_free(c, p->d_lists);
+    pool_free(c, p->d_rowcnt); pool_free(c, p->d_cptr); pool_free(c, p->d_lists); pool_free(c, p->d_tail);
     delete p;
 }
 extern "C" int64_t smm_plan_nnz(const smm_plan *p) { return p ? p->nnz : -1; }
@@ -1189,14 +1190,15 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
             PCHK(ensure_pack(c, b, p->g, &p->pack));
         }
         PCHK(pool_get(c, (size_t)a->nnz * (p->g.nct + 1), &p->d_runs));
+        PCHK(pool_get(c, (size_t)m, &p->d_tail));
         const int nd = p->n_bin[2];
         const int rgrid = (int)std::min<int64_t>((nd + 3) / 4, 65536);
         if (p->list16)
             LAUNCH(c, "smm_runs", smm_runs<unsigned short>, rgrid, 256, 0, nd, p->g.nct, p->g.wc, (const int *)(p->d_lists + 2 * m), a->ptr,
-                   p->d_ub_off, p->d_rowcnt, p->d_P, (const unsigned short *)p->d_tmp, p->d_runs);
+                   p->d_ub_off, p->d_rowcnt, p->d_P, (const unsigned short *)p->d_tmp, p->d_runs, p->d_tail);
         else
             LAUNCH(c, "smm_runs", smm_runs<int>, rgrid, 256, 0, nd, p->g.nct, p->g.wc, (const int *)(p->d_lists + 2 * m), a->ptr,
-                   p->d_ub_off, p->d_rowcnt, p->d_P, (const int *)p->d_tmp, p->d_runs);
+                   p->d_ub_off, p->d_rowcnt, p->d_P, (const int *)p->d_tmp, p->d_runs, p->d_tail);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "smm_runs: %s", hipGetErrorString(e)); }
     }
@@ -1260,7 +1262,7 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
         A.tdesc = p->pack.desc; A.tpay = p->pack.pay;
         A.rowsB = (int)p->b->rows;
         A.c_ptr = p->d_cptr; A.c_idx = d_c_indices; A.c_val = d_c_data;
-        A.ub_off = p->d_ub_off; A.tmp_idx = p->d_tmp; A.list16 = p->list16 ? 1 : 0; A.runs = p->d_runs;
+        A.ub_off = p->d_ub_off; A.tmp_idx = p->d_tmp; A.list16 = p->list16 ? 1 : 0; A.runs = p->d_runs; A.tail = p->d_tail;
         if (p->use_slab) {
             // values in column order into a dense scratch (one row per row of the bin), then the emission
             double *scratch = nullptr;

@@ -619,6 +619,12 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, const int *__restrict
 // row's list: the wave copies the list into LDS with coalesced loads, RUNS_WIN entries at a time (the
 // next window is already on its way while one is searched), and the lanes search there (a first version searched in global memory: ~70 dependent probes per lane into
 // lines nobody else used, 19 ms at 200 000 columns / 10 tiles; this one streams the list once).
+// The TAIL of a row: from the first step e0 after which every step appends fewer than TAIL_MIN columns, the
+// sub-runs are a few entries each (at 99 % fill the last 60 % of the steps hold 13 % of a row) -- one chunk
+// load and two partial stores per sub-run.  Those steps get no sub-run table: the numeric epilogue walks the
+// list positions [P[e0], end) contiguously, 64 at a time, and every tile's unit keeps the columns that are
+// its own (positions in the list ARE positions in the result).  tail[row] = {e0, P[e0]}.
+constexpr int TAIL_MIN = 64;
 constexpr int RUNS_WIN = 2048;
 template <typename LT>
 __global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc, const int *__restrict__ rowlist,
@@ -627,7 +633,7 @@ __global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc, const in
                                                 const int *__restrict__ rowcnt,
                                                 const unsigned *__restrict__ P,
                                                 const LT *__restrict__ tmp_idx,
-                                                unsigned *__restrict__ runs)
+                                                unsigned *__restrict__ runs, int2 *__restrict__ tail)
 {
     __shared__ int win_all[4][RUNS_WIN];
     constexpr int NV = RUNS_WIN / WAVE;            // window elements per lane
@@ -639,6 +645,18 @@ __global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc, const in
         const int a0 = a_ptr[row], a1 = a_ptr[row + 1];
         const LT *__restrict__ list = tmp_idx + ub_off[row];
         const unsigned total = (unsigned)rowcnt[row];
+        // where the tail starts: one pass over P (coalesced)
+        int e_last = a0 - 1;
+        for (int eb = a0; eb < a1; eb += WAVE) {
+            const int e = eb + lane;
+            if (e < a1) {
+                const unsigned q0 = P[e], q1 = e + 1 < a1 ? P[e + 1] : total;
+                if (q1 - q0 >= (unsigned)TAIL_MIN) e_last = e;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(e_last, o); e_last = y > e_last ? y : e_last; }
+        const int e0 = e_last + 1;                  // steps e0 .. a1-1 form the tail
+        if (lane == 0) tail[row] = make_int2(e0, (int)(e0 < a1 ? P[e0] : total));
         // The row's list is cut into fixed windows of RUNS_WIN entries.  Window k sits in LDS while
         // window k+1 travels in registers (its loads are issued before the searches in window k).
         int v[NV];
@@ -651,12 +669,12 @@ __global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc, const in
         };
         unsigned cur = 0xffffffffu;                 // start of the window that is in LDS
         if (total) fetch(0);
-        for (int eb = a0; eb < a1; eb += WAVE) {
+        for (int eb = a0; eb < e0; eb += WAVE) {
             const int e = eb + lane;
-            const bool valid = e < a1;
+            const bool valid = e < e0;
             const unsigned p0 = valid ? P[e] : total;
             const unsigned p1 = (valid && e + 1 < a1) ? P[e + 1] : total;
-            unsigned *r = runs + (size_t)(valid ? e : a1 - 1) * (nct + 1);
+            unsigned *r = runs + (size_t)(valid ? e : e0 - 1) * (nct + 1);
             int tcur = 1;                           // next boundary this lane has to place
             if (valid) {
                 r[0] = p0; r[nct] = p1;
@@ -730,7 +748,8 @@ struct NumericArgs {
     const int64_t *c_ptr; int *c_idx; double *c_val;
     const int64_t *ub_off; const void *tmp_idx;  // ordered column lists of smm_symbolic (int32, or uint16 when list16)
     int list16;
-    const unsigned *runs;           // [nnzA][nct+1] sub-run table (smm_runs)
+    const unsigned *runs;           // [nnzA][nct+1] sub-run table (smm_runs), steps before the tail
+    const int2 *tail;               // [rows] {first step of the tail, its list position}
     const int *rowlist;             // rows handled by this launch (NULL = all m rows)
     unsigned long long *stamps;     // diagnostic builds (-DSMM_STAMPS) only: 4 phase totals
     // dense output
@@ -1010,10 +1029,12 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
         int *__restrict__ oi = A.c_idx + rs;
         double *__restrict__ ov = A.c_val + rs;
         const size_t per = (size_t)A.nct + 1;
-        for (int rb = a0; rb < a1; rb += NW * WAVE) {
+        const int2 tl = A.tail[row];
+        const int e0 = tl.x;
+        for (int rb = a0; rb < e0; rb += NW * WAVE) {
             const int e = rb + wave + NW * lane;
-            const bool ev = e < a1;
-            const unsigned *rp = A.runs + (size_t)(ev ? e : a1 - 1) * per + tc;
+            const bool ev = e < e0;
+            const unsigned *rp = A.runs + (size_t)(ev ? e : e0 - 1) * per + tc;
             const unsigned r0 = rp[0];
             const unsigned r1 = ev ? rp[1] : r0;
             const int nch = (int)((r1 - r0 + WAVE - 1) >> 6);
@@ -1037,6 +1058,27 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
 #pragma unroll
                 for (int u = 0; u < EPI_UNROLL; ++u)        // idle lanes read the dummy word: -1, or 0xffff as uint16 (no column: B has < 65 535)
                     if (L16 ? c[u] != 0xffff : c[u] >= 0) { st_stream(&oi[sl[u]], c[u]); st_stream(&ov[sl[u]], acc[c[u] - lo_c]); }
+            }
+        }
+        // the tail (see TAIL_MIN): list positions [tl.y, row length) 64 at a time, this tile's columns kept.
+        // (the dummy word of idle lanes, -1 or 0xffff, lies in no tile: B has < 65 535 columns when lists are 16-bit)
+        const unsigned rowlen = (unsigned)(A.c_ptr[row + 1] - rs), tail0 = (unsigned)tl.y;
+        const unsigned ntc = rowlen > tail0 ? (rowlen - tail0 + WAVE - 1) >> 6 : 0u;
+        for (unsigned q0 = (unsigned)wave; q0 < ntc; q0 += NW * EPI_UNROLL) {
+            int c[EPI_UNROLL];
+            unsigned ps[EPI_UNROLL];
+#pragma unroll
+            for (int u = 0; u < EPI_UNROLL; ++u) {
+                const unsigned q = q0 + (unsigned)u * NW;
+                ps[u] = tail0 + (q << 6) + (unsigned)lane;
+                const bool p = q < ntc && ps[u] < rowlen;
+                const LT *ip = p ? list + ps[u] : (const LT *)A.dummy_idx;
+                c[u] = (int)ld_stream(ip);
+            }
+#pragma unroll
+            for (int u = 0; u < EPI_UNROLL; ++u) {
+                const unsigned cc = (unsigned)(c[u] - lo_c);
+                if (cc < (unsigned)w) { st_stream(&oi[ps[u]], c[u]); st_stream(&ov[ps[u]], acc[cc]); }
             }
         }
     }
