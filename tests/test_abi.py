@@ -96,3 +96,29 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.lower().replace("oracle/ ", ""), f"{f} mentions the oracle"
+
+
+def test_modifyalloc_resizes_and_frees_like_the_reference():
+    """reference src/memfunctions.cpp:77-103: realloc colInd / values to new_size (contents kept), free both and
+    NULL them for new_size <= 0.  Host-only: no GPU involved."""
+    class SparseMat(ctypes.Structure):
+        _fields_ = [("nzmax", ctypes.c_int), ("rows", ctypes.c_int), ("cols", ctypes.c_int),
+                    ("rowPtr", ctypes.POINTER(ctypes.c_int)), ("colInd", ctypes.POINTER(ctypes.c_int)),
+                    ("values", ctypes.POINTER(ctypes.c_double))]
+    from sparse_matrix_mult_amd._lib import LIB_PATH
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.create_sparsemat.restype = ctypes.POINTER(SparseMat)
+    lib.create_sparsemat.argtypes = [ctypes.c_int] * 3
+    lib.modifyalloc.argtypes = [ctypes.POINTER(SparseMat), ctypes.c_int]
+    lib.destroy_sparsemat.argtypes = [ctypes.POINTER(SparseMat)]
+    m = lib.create_sparsemat(2, 3, 4).contents
+    for i in range(4):
+        m.colInd[i], m.values[i] = i + 1, 0.5 * i
+    lib.modifyalloc(ctypes.byref(m), 100000)                       # grow: the first entries survive
+    assert [m.colInd[i] for i in range(4)] == [1, 2, 3, 4] and [m.values[i] for i in range(4)] == [0.0, 0.5, 1.0, 1.5]
+    m.colInd[99999], m.values[99999] = 7, 7.0                      # the new capacity is writable
+    lib.modifyalloc(ctypes.byref(m), 2)                            # shrink
+    assert (m.colInd[0], m.colInd[1], m.values[1]) == (1, 2, 0.5)
+    lib.modifyalloc(ctypes.byref(m), 0)                            # <= 0: free and NULL, rowPtr untouched
+    assert not m.colInd and not m.values and bool(m.rowPtr)
+    lib.destroy_sparsemat(ctypes.byref(m))

@@ -202,3 +202,34 @@ def test_config4_one_rank_share_of_200k(ctx, oracle, tdev, exact):
     _check_sparse_sample(oracle, a_h, b_h, n, (indptr, indices, data), 12345, 12345 + 120, exact)
     lin = _scipy(a_h, (m, n)) @ (_scipy(b_h, (n, n)) @ np.ones(n))
     assert rel_err(_row_sums(torch, indptr, data).cpu().numpy(), lin) <= LIN_RTOL
+
+
+def test_legacy_abi_refuses_a_result_beyond_int32_loudly(c1, capfd):
+    """SURVEY 8b "Limits": the reference's structs hold nnz / rowPtr as int.  configs[1] has 2.48e9 output
+    nonzeros: through the legacy symbol the call must fail LOUDLY -- a message on stderr and an empty output
+    struct (nzmax 0, NULL arrays), never a truncated matrix (reference error convention)."""
+    import ctypes
+
+    class SparseMat(ctypes.Structure):
+        _fields_ = [("nzmax", ctypes.c_int), ("rows", ctypes.c_int), ("cols", ctypes.c_int),
+                    ("rowPtr", ctypes.POINTER(ctypes.c_int)), ("colInd", ctypes.POINTER(ctypes.c_int)),
+                    ("values", ctypes.POINTER(ctypes.c_double))]
+    from sparse_matrix_mult_amd._lib import LIB_PATH
+    lib = ctypes.CDLL(LIB_PATH)
+    sp_ = ctypes.POINTER(SparseMat)
+    lib.create_sparsemat.argtypes = [ctypes.c_int] * 3; lib.create_sparsemat.restype = sp_
+    lib.sparse_nosym.argtypes = [sp_, sp_, sp_, ctypes.c_int]; lib.sparse_nosym.restype = None
+    lib.destroy_sparsemat.argtypes = [sp_]
+    ops = []
+    for h in (c1["a_h"], c1["b_h"]):
+        s = lib.create_sparsemat(c1["m"], c1["n"], int(h[0][-1])).contents
+        for dst, src in ((s.rowPtr, h[0]), (s.colInd, h[1]), (s.values, h[2])):
+            ctypes.memmove(dst, src.ctypes.data, src.nbytes)
+        ops.append(s)
+    out = SparseMat()
+    lib.sparse_nosym(ctypes.byref(ops[0]), ctypes.byref(ops[1]), ctypes.byref(out), 5)
+    err = capfd.readouterr().err
+    assert out.nzmax == 0 and not out.colInd and not out.values
+    assert "2^31" in err or "int32" in err or "INT_MAX" in err or "overflow" in err.lower(), err
+    for s in ops:
+        lib.destroy_sparsemat(ctypes.byref(s))
