@@ -15,6 +15,7 @@ same argument meaning, same return types, same raised errors.  What differs:
 import collections
 import os
 import threading
+import weakref
 import zlib
 
 import numpy as np
@@ -61,12 +62,13 @@ def set_exact(flag):
 # the last few uploaded CSR operands stay resident in HBM together with what the kernels derive from
 # them (validation, tile index, tile-local columns, the sliced-ELL copy of H): a repeated operand
 # skips the upload and all of that.  An entry is recognised by the IDENTITY of the caller's three
-# arrays (address, length, dtype) and the shape, plus a checksum of a strided sample (<= 4096 elements
-# of each array and both ends) -- so replacing a matrix, or editing it anywhere the sample looks, is
+# arrays -- the very same numpy objects, held by weak reference, so a freed array whose address is
+# re-used can never be mistaken for it -- and the shape, plus a checksum of a strided sample (<= 4096
+# elements of each array and both ends): replacing a matrix, or editing it anywhere the sample looks, is
 # seen; an in-place edit of a few entries between two calls may not be: call clear_cache() after
 # editing an operand in place, or switch the cache off (SMM_OPERAND_CACHE=0 / set_operand_cache(0)).
 _cache_lock = threading.Lock()
-_cache = collections.OrderedDict()          # key -> DeviceCSR; most recently used last
+_cache = collections.OrderedDict()          # key -> (DeviceCSR, weak references to the three arrays); most recently used last
 _cache_entries = int(os.environ.get("SMM_OPERAND_CACHE", "4"))
 _cache_max_bytes = int(float(os.environ.get("SMM_OPERAND_CACHE_GB", "16")) * (1 << 30))
 
@@ -95,21 +97,25 @@ def _upload(ctx, m):
     if _cache_entries <= 0:
         return ctx.csr_from_scipy(m), True
     key = _operand_key(m)
+    arrs = (m.indptr, m.indices, m.data)
     with _cache_lock:
-        h = _cache.get(key)
-        if h is not None and h.handle and h.ctx is ctx:
-            _cache.move_to_end(key)
-            return h, False
+        hit = _cache.get(key)
+        if hit is not None:
+            h, refs = hit
+            if h.handle and h.ctx is ctx and all(r() is a for r, a in zip(refs, arrs)):
+                _cache.move_to_end(key)
+                return h, False
+            del _cache[key]                          # same address and sample, other arrays: a stale entry
     h = ctx.csr_from_scipy(m)
     if _operand_bytes(h) > _cache_max_bytes:
         return h, True
     with _cache_lock:
-        _cache[key] = h
+        _cache[key] = (h, tuple(weakref.ref(a) for a in arrs))
         _cache.move_to_end(key)
-        total = sum(_operand_bytes(v) for v in _cache.values())
+        total = sum(_operand_bytes(v[0]) for v in _cache.values())
         while len(_cache) > _cache_entries or total > _cache_max_bytes:
             _, old = _cache.popitem(last=False)      # dropped here; freed when the last user lets go of it
-            total -= _operand_bytes(old)
+            total -= _operand_bytes(old[0])
     return h, False
 
 
