@@ -825,8 +825,7 @@ static int ensure_pack(smm_ctx *c, smm_csr *b, const Geom &g, smm_csr::PackCache
     CHK(pool_get(c, (size_t)std::max<int64_t>(cells, 1), &units));
     int rc = pool_get(c, (size_t)cells + 1, &off64);
     if (rc != SMM_OK) { pool_free(c, units); return rc; }
-    const int nw = g.n_ft / std::max(g.nct, 1);                  // fine tiles per coarse tile (1 for the shared walk)
-    if (cells > 0) LAUNCH(c, "smm_pack_count", smm_pack_count, (cells + 255) / 256, 256, 0, (int)b->rows, np, nw, seg, units);
+    if (cells > 0) LAUNCH(c, "smm_pack_count", smm_pack_count, (cells + 255) / 256, 256, 0, (int)b->rows, np, seg, units);
     rc = scan_launch<int>(c, cells, units, off64);
     int64_t total = 0;
     if (rc == SMM_OK) {
@@ -843,8 +842,8 @@ static int ensure_pack(smm_ctx *c, smm_csr *b, const Geom &g, smm_csr::PackCache
         rc = fail(SMM_ERR_ALLOC, "hipMalloc of the packed payload failed");
     }
     if (rc == SMM_OK && cells > 0) {
-        LAUNCH(c, "smm_pack_desc", smm_pack_desc, (cells + 255) / 256, 256, 0, (int)b->rows, np, nw, seg, (const int64_t *)off64, e.desc);
-        LAUNCH(c, "smm_pack_fill", smm_pack_fill, std::min<int64_t>((b->rows + 3) / 4, 65536), 256, 0, (int)b->rows, np, nw, pw, g.wc, b->ptr,
+        LAUNCH(c, "smm_pack_desc", smm_pack_desc, (cells + 255) / 256, 256, 0, (int)b->rows, np, seg, (const int64_t *)off64, e.desc);
+        LAUNCH(c, "smm_pack_fill", smm_pack_fill, std::min<int64_t>((b->rows + 3) / 4, 65536), 256, 0, (int)b->rows, np, pw, g.wc, b->ptr,
                b->idx, b->val, seg, (const int2 *)e.desc, e.pay);
         hipError_t he = hipGetLastError();
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);        // units / off64 go back to the pool

@@ -205,43 +205,40 @@ __global__ __launch_bounds__(256) void smm_segptr(int rows, int n_ft, int wf,
 // Packed tile-major payload of a sorted operand for the numeric walks: the piece of row j inside tile t (a
 // coarse tile for the shared walk, a fine tile for the exact walk; np tiles of pw columns) is ONE contiguous
 // block -- its values (f64) followed by its columns relative to the COARSE tile (c mod wc, int16, padded to 8
-// bytes).  Blocks are ordered coarse tile, row, fine tile: the nw fine pieces of one row inside a coarse tile
-// are neighbours (the 8 waves of an exact workgroup read them together; a fine-tile-major order cost the exact
-// walk 12 %).  desc[(tc*rows + j)*nw + w] = {first 8-byte unit, entries}.  Against separate loc16[] / val[] arrays in CSR order a piece touches two partial cache lines
+// bytes) -- and the blocks of a tile follow each other in row order.  desc[t*rows + j] = {first 8-byte unit,
+// entries}.  Against separate loc16[] / val[] arrays in CSR order a piece touches two partial cache lines
 // instead of four (-13 GB of fabric reads per 50k x 50k product), and its bounds are one 8-byte load.
-__global__ __launch_bounds__(256) void smm_pack_count(int rows, int np, int nw, const int *__restrict__ seg, int *__restrict__ units)
+__global__ __launch_bounds__(256) void smm_pack_count(int rows, int nct, const int *__restrict__ seg, int *__restrict__ units)
 {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (int64_t)rows * np) return;
-    const int64_t per = (int64_t)rows * nw;
-    const int tc = (int)(gid / per), j = (int)((gid % per) / nw), w = (int)(gid % nw);
-    const int *sp = seg + (size_t)j * (np + 1) + tc * nw + w;
+    if (gid >= (int64_t)rows * nct) return;
+    const int t = (int)(gid / rows), j = (int)(gid % rows);
+    const int *sp = seg + (size_t)j * (nct + 1) + t;
     const int len = sp[1] - sp[0];
     units[gid] = len + ((len + 3) >> 2);
 }
-__global__ __launch_bounds__(256) void smm_pack_desc(int rows, int np, int nw, const int *__restrict__ seg, const int64_t *__restrict__ off,
+__global__ __launch_bounds__(256) void smm_pack_desc(int rows, int nct, const int *__restrict__ seg, const int64_t *__restrict__ off,
                                                      int2 *__restrict__ desc)
 {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (int64_t)rows * np) return;
-    const int64_t per = (int64_t)rows * nw;
-    const int tc = (int)(gid / per), j = (int)((gid % per) / nw), w = (int)(gid % nw);
-    const int *sp = seg + (size_t)j * (np + 1) + tc * nw + w;
+    if (gid >= (int64_t)rows * nct) return;
+    const int t = (int)(gid / rows), j = (int)(gid % rows);
+    const int *sp = seg + (size_t)j * (nct + 1) + t;
     desc[gid] = make_int2((int)off[gid], sp[1] - sp[0]);
 }
 // one wave per row of the operand
-__global__ __launch_bounds__(256) void smm_pack_fill(int rows, int np, int nw, int pw, int wc, const int *__restrict__ ptr,
-                                                     const int *__restrict__ idx, const double *__restrict__ val,
-                                                     const int *__restrict__ seg, const int2 *__restrict__ desc, double *__restrict__ pay)
+__global__ __launch_bounds__(256) void smm_pack_fill(int rows, int nct, int pw, int wc, const int *__restrict__ ptr, const int *__restrict__ idx,
+                                                     const double *__restrict__ val, const int *__restrict__ seg,
+                                                     const int2 *__restrict__ desc, double *__restrict__ pay)
 {
     const int lane = lane_id();
     const int wpb = blockDim.x / WAVE;
     for (int j = blockIdx.x * wpb + (threadIdx.x >> 6); j < rows; j += gridDim.x * wpb) {
-        const int *sp = seg + (size_t)j * (np + 1);
+        const int *sp = seg + (size_t)j * (nct + 1);
         for (int k = ptr[j] + lane; k < ptr[j + 1]; k += WAVE) {
             const int c = idx[k];
-            const int t = c / pw;                       // fine tile; coarse tile t / nw
-            const int2 d = desc[((size_t)(t / nw) * rows + j) * nw + t % nw];
+            const int t = c / pw;
+            const int2 d = desc[(size_t)t * rows + j];
             const int pos = k - sp[t];
             pay[d.x + pos] = val[k];
             ((short *)(pay + d.x + d.y))[pos] = (short)(c % wc);
@@ -774,8 +771,7 @@ __device__ __forceinline__ void smm_accumulate(const NumericArgs &A, double *__r
                                                const int thresh, const int a0, const int a1, const int ft)
 {
     const int lane = lane_id();
-    const int nw = A.n_ft / A.nct;                                       // fine tiles per coarse tile
-    const int2 *__restrict__ desc = A.tdesc + (size_t)(ft / nw) * A.rowsB * nw + ft % nw;   // this wave's piece of every row
+    const int2 *__restrict__ desc = A.tdesc + (size_t)ft * A.rowsB;     // pieces of fine tile ft
     const double *__restrict__ bv = A.tpay;
     const short *__restrict__ bi = (const short *)A.tpay;
     const short *__restrict__ dummy_c = (const short *)A.dummy_idx;
@@ -789,7 +785,7 @@ __device__ __forceinline__ void smm_accumulate(const NumericArgs &A, double *__r
     };
     // piece of row r: s = first 8-byte unit (values), en = s + entries; its columns are the shorts from unit en on
     auto load_seg = [&](int r, int &s, int &en) {
-        const int2 d = desc[(size_t)r * nw];
+        const int2 d = desc[r];
         s = d.x;
         en = d.x + d.y;
     };
