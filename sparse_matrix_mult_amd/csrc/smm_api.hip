@@ -442,9 +442,11 @@ struct smm_csr {
     // plans keep the pointer of theirs, so a later product with another geometry (SMM_EXACT vs
     // default, another tuning, the ELL chunks of the triple product) never invalidates it
     struct SegCache { int wf, n_ft; int *seg; };
+    struct LocCache { int wc; short *loc; };          // tile-local columns for coarse width wc
     struct SlabCache { int ws, n_slabs; int *soff; short *scol; double *sval; };   // slab-major copy (smm_slab.hpp)
     std::vector<SegCache> segs;
-    struct PackCache { int pw, np, wc; int2 *desc; double *pay; };   // packed tile-major payload (smm_pack_*): np tiles of pw columns
+    std::vector<LocCache> locs;
+    struct PackCache { int wc, nct; int2 *desc; double *pay; };   // packed tile-major payload (smm_pack_*)
     std::vector<SlabCache> slabs;
     std::vector<PackCache> packs;
     unsigned short *idx16 = nullptr;             // 16-bit copy of idx (cols < 65535): the symbolic phase's gather stream
@@ -536,6 +538,7 @@ extern "C" void smm_csr_destroy(smm_csr *m)
     (void)hipStreamSynchronize(m->ctx->stream);
     if (m->owned) { (void)hipFree((void *)m->ptr); (void)hipFree((void *)m->idx); (void)hipFree((void *)m->val); }
     for (auto &e : m->segs) (void)hipFree(e.seg);
+    for (auto &e : m->locs) (void)hipFree(e.loc);
     for (auto &e : m->slabs) { (void)hipFree(e.soff); (void)hipFree(e.scol); (void)hipFree(e.sval); }
     for (auto &e : m->packs) { (void)hipFree(e.desc); (void)hipFree(e.pay); }
     (void)hipFree(m->idx16);
@@ -617,6 +620,24 @@ static int ensure_idx16(smm_ctx *c, smm_csr *b)
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { (void)hipFree(b->idx16); b->idx16 = nullptr; return fail(SMM_ERR_HIP, "smm_idx16: %s", hipGetErrorString(e)); }
     }
+    return SMM_OK;
+}
+
+static int ensure_loc(smm_ctx *c, smm_csr *b, const Geom &g, const short **out)
+{
+    for (auto &e : b->locs)
+        if (e.wc == g.wc) { *out = e.loc; return SMM_OK; }
+    if (g.wc > 32767) return fail(SMM_ERR_INVALID, "coarse tile wider than 32767 columns");
+    short *loc = nullptr;
+    if (hipMalloc((void **)&loc, std::max<int64_t>(b->nnz, 1) * sizeof(short)) != hipSuccess)
+        return fail(SMM_ERR_ALLOC, "hipMalloc of the tile-local column array failed");
+    if (b->nnz > 0) {
+        LAUNCH(c, "smm_loc16", smm_loc16, std::min<int64_t>((b->nnz + 255) / 256, 65536), 256, 0, (int)b->nnz, g.wc, b->idx, loc);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { (void)hipFree(loc); return fail(SMM_ERR_HIP, "smm_loc16: %s", hipGetErrorString(e)); }
+    }
+    b->locs.push_back({g.wc, loc});
+    *out = loc;
     return SMM_OK;
 }
 
@@ -764,7 +785,9 @@ struct smm_plan {
     unsigned *d_P = nullptr;       // nnz(A)
     unsigned *d_runs = nullptr;    // nnz(A) x (nct+1)
     int2 *d_tail = nullptr;        // m: where the tail of every row starts (smm_runs)
-    smm_csr::PackCache pack{0, 0, 0, nullptr, nullptr};   // packed payload of B for geometry g (owned by b)
+    const int *seg = nullptr;      // B's tile index and tile-local columns for geometry g (owned by b)
+    const short *loc = nullptr;
+    smm_csr::PackCache pack{0, 0, nullptr, nullptr};   // default mode: packed payload of B for geometry g
     bool use_slab = false;         // dense-bin rows: smm_dense_slab -> scratch -> emission, instead of the tile kernel
     SlabGeom sg{};
     smm_csr::SlabCache slab{0, 0, nullptr, nullptr, nullptr};
@@ -812,20 +835,19 @@ static int scan_launch(smm_ctx *c, int64_t n, const T *in, int64_t *out)
 // (descriptors are handed out BY VALUE: a plan must not point into the operand's vector, which may grow)
 static int ensure_pack(smm_ctx *c, smm_csr *b, const Geom &g, smm_csr::PackCache *out)
 {
-    // shared walk (wf == wc): one piece per coarse tile; exact walk: one per fine tile
-    const int pw = g.wf, np = g.n_ft;
     for (auto &e : b->packs)
-        if (e.pw == pw && e.np == np && e.wc == g.wc) { *out = e; return SMM_OK; }
+        if (e.wc == g.wc && e.nct == g.nct) { *out = e; return SMM_OK; }
     if (g.wc > 32767) return fail(SMM_ERR_INVALID, "coarse tile wider than 32767 columns");
+    Geom gs = g; gs.wf = g.wc; gs.n_ft = g.nct;               // the coarse-tile index (shared walk: one entry per coarse tile)
     const int *seg = nullptr;
-    CHK(ensure_seg(c, b, g, &seg));
-    const int64_t cells = (int64_t)np * b->rows;
+    CHK(ensure_seg(c, b, gs, &seg));
+    const int64_t cells = (int64_t)g.nct * b->rows;
     if (cells + 1 >= INT32_MAX) return fail(SMM_ERR_INVALID, "too many (tile, row) pieces");
     int *units = nullptr; int64_t *off64 = nullptr;
     CHK(pool_get(c, (size_t)std::max<int64_t>(cells, 1), &units));
     int rc = pool_get(c, (size_t)cells + 1, &off64);
     if (rc != SMM_OK) { pool_free(c, units); return rc; }
-    if (cells > 0) LAUNCH(c, "smm_pack_count", smm_pack_count, (cells + 255) / 256, 256, 0, (int)b->rows, np, seg, units);
+    if (cells > 0) LAUNCH(c, "smm_pack_count", smm_pack_count, (cells + 255) / 256, 256, 0, (int)b->rows, g.nct, seg, units);
     rc = scan_launch<int>(c, cells, units, off64);
     int64_t total = 0;
     if (rc == SMM_OK) {
@@ -833,8 +855,8 @@ static int ensure_pack(smm_ctx *c, smm_csr *b, const Geom &g, smm_csr::PackCache
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) rc = fail(SMM_ERR_HIP, "pack build: %s", hipGetErrorString(e));
     }
-    if (rc == SMM_OK && total >= INT32_MAX / 4) rc = fail(SMM_ERR_INVALID, "operand too large for the packed payload");
-    smm_csr::PackCache e{pw, np, g.wc, nullptr, nullptr};
+    if (rc == SMM_OK && total >= INT32_MAX) rc = fail(SMM_ERR_INVALID, "operand too large for the packed payload");
+    smm_csr::PackCache e{g.wc, g.nct, nullptr, nullptr};
     if (rc == SMM_OK &&
         (hipMalloc((void **)&e.desc, (size_t)std::max<int64_t>(cells, 1) * sizeof(int2)) != hipSuccess ||
          hipMalloc((void **)&e.pay, (size_t)std::max<int64_t>(total, 1) * sizeof(double)) != hipSuccess)) {
@@ -842,8 +864,8 @@ static int ensure_pack(smm_ctx *c, smm_csr *b, const Geom &g, smm_csr::PackCache
         rc = fail(SMM_ERR_ALLOC, "hipMalloc of the packed payload failed");
     }
     if (rc == SMM_OK && cells > 0) {
-        LAUNCH(c, "smm_pack_desc", smm_pack_desc, (cells + 255) / 256, 256, 0, (int)b->rows, np, seg, (const int64_t *)off64, e.desc);
-        LAUNCH(c, "smm_pack_fill", smm_pack_fill, std::min<int64_t>((b->rows + 3) / 4, 65536), 256, 0, (int)b->rows, np, pw, g.wc, b->ptr,
+        LAUNCH(c, "smm_pack_desc", smm_pack_desc, (cells + 255) / 256, 256, 0, (int)b->rows, g.nct, seg, (const int64_t *)off64, e.desc);
+        LAUNCH(c, "smm_pack_fill", smm_pack_fill, std::min<int64_t>((b->rows + 3) / 4, 65536), 256, 0, (int)b->rows, g.nct, g.wc, b->ptr,
                b->idx, b->val, seg, (const int2 *)e.desc, e.pay);
         hipError_t he = hipGetLastError();
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);        // units / off64 go back to the pool
@@ -1161,7 +1183,12 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
                       slab_pays(c, a, p->sg, (double)p->n_bin[2] * (double)p->ncols, est_products, (double)p->nnz,
                                 (double)b->nnz / (double)std::max<int64_t>(b->rows, 1), (double)p->ncols);
         if (p->use_slab) PCHK(ensure_slab(c, b, p->sg, &p->slab));
-        else PCHK(ensure_pack(c, b, p->g, &p->pack));
+        else if (flags & SMM_EXACT) {
+            PCHK(ensure_seg(c, b, p->g, &p->seg));
+            PCHK(ensure_loc(c, b, p->g, &p->loc));
+        } else {
+            PCHK(ensure_pack(c, b, p->g, &p->pack));
+        }
         PCHK(pool_get(c, (size_t)a->nnz * (p->g.nct + 1), &p->d_runs));
         PCHK(pool_get(c, (size_t)m, &p->d_tail));
         const int nd = p->n_bin[2];
@@ -1231,7 +1258,7 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
         A.row_offset = p->row_offset;
         A.rowlist = dense_rows;
         A.a_ptr = p->a->ptr; A.a_idx = p->a->idx; A.a_val = p->a->val;
-        A.b_idx = p->b->idx; A.b_val = p->b->val;
+        A.b_idx = p->b->idx; A.b_val = p->b->val; A.seg = p->seg; A.b_loc = p->loc;
         A.tdesc = p->pack.desc; A.tpay = p->pack.pay;
         A.rowsB = (int)p->b->rows;
         A.c_ptr = p->d_cptr; A.c_idx = d_c_indices; A.c_val = d_c_data;
@@ -1333,13 +1360,19 @@ static int dense_into(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t row
     }
     if (!(b->vflags & CSR_UNSORTED)) {
         Geom g = make_geom(c, n, b, (flags & SMM_EXACT) != 0);
-        smm_csr::PackCache pack{0, 0, 0, nullptr, nullptr};
-        CHK(ensure_pack(c, b, g, &pack));
+        const int *seg = nullptr; const short *loc = nullptr;
+        smm_csr::PackCache pack{0, 0, nullptr, nullptr};
+        if (flags & SMM_EXACT) {
+            CHK(ensure_seg(c, b, g, &seg));
+            CHK(ensure_loc(c, b, g, &loc));
+        } else {
+            CHK(ensure_pack(c, b, g, &pack));
+        }
         NumericArgs A{};
         A.m = (int)m; A.ncols = (int)n; A.nct = g.nct; A.wc = g.wc; A.wf = g.wf; A.n_ft = g.n_ft;
         A.row_offset = row_offset;
         A.a_ptr = a->ptr; A.a_idx = a->idx; A.a_val = a->val;
-        A.b_idx = b->idx; A.b_val = b->val;
+        A.b_idx = b->idx; A.b_val = b->val; A.seg = seg; A.b_loc = loc;
         A.tdesc = pack.desc; A.tpay = pack.pay;
         A.rowsB = (int)b->rows;
         A.c_dense = d_c; A.ldc = ldc;
@@ -1429,7 +1462,7 @@ extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags,
     CHK(pool_get(c, (size_t)nr * K, &T));
     if (q->cols < K) HIPCHK(hipMemsetAsync(T, 0, (size_t)nr * K * sizeof(double), c->stream));
     smm_csr hv = *h;                       // row-range view of H (borrowed arrays)
-    hv.ptr = h->ptr + row_begin; hv.rows = nr; hv.owned = false; hv.segs.clear(); hv.slabs.clear(); hv.packs.clear(); hv.idx16 = nullptr;
+    hv.ptr = h->ptr + row_begin; hv.rows = nr; hv.owned = false; hv.segs.clear(); hv.locs.clear(); hv.slabs.clear(); hv.packs.clear(); hv.idx16 = nullptr;
     // indptr of the view is not rebased: kernels only use ptr[row], ptr[row+1] as absolute positions.
     int rc = dense_into(c, &hv, q, flags & SMM_EXACT, 0, T, K);
     if (rc != SMM_OK) { pool_free(c, T); return rc; }

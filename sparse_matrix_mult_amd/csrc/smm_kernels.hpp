@@ -202,12 +202,22 @@ __global__ __launch_bounds__(256) void smm_segptr(int rows, int n_ft, int wf,
     seg[gid] = lo;
 }
 
-// Packed tile-major payload of a sorted operand for the numeric walks: the piece of row j inside tile t (a
-// coarse tile for the shared walk, a fine tile for the exact walk; np tiles of pw columns) is ONE contiguous
-// block -- its values (f64) followed by its columns relative to the COARSE tile (c mod wc, int16, padded to 8
+// ---------------------------------------------------------------------------------------
+// Tile-local column of every entry of a sorted operand: loc[k] = idx[k] mod wc as int16 (a
+// coarse tile is at most 20 000 columns wide).  The numeric walks read these 2 bytes instead
+// of the 4-byte global column: 10 instead of 12 bytes per product on the dominant gather.
+__global__ __launch_bounds__(256) void smm_loc16(int nnz, int wc, const int *__restrict__ idx,
+                                                 short *__restrict__ loc)
+{
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += gridDim.x * blockDim.x)
+        loc[k] = (short)(idx[k] % wc);
+}
+
+// Packed tile-major payload of a sorted operand for the shared-tile walk: the piece of row j inside coarse
+// tile t is ONE contiguous block -- its values (f64) followed by its tile-local columns (int16, padded to 8
 // bytes) -- and the blocks of a tile follow each other in row order.  desc[t*rows + j] = {first 8-byte unit,
-// entries}.  Against separate loc16[] / val[] arrays in CSR order a piece touches two partial cache lines
-// instead of four (-13 GB of fabric reads per 50k x 50k product), and its bounds are one 8-byte load.
+// entries}.  Against the separate loc16[] / val[] arrays in CSR order a piece touches two partial cache lines
+// instead of four (-12 GB of fabric reads per 50k x 50k product), and its bounds are one 8-byte load.
 __global__ __launch_bounds__(256) void smm_pack_count(int rows, int nct, const int *__restrict__ seg, int *__restrict__ units)
 {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(256) void smm_pack_desc(int rows, int nct, const in
     desc[gid] = make_int2((int)off[gid], sp[1] - sp[0]);
 }
 // one wave per row of the operand
-__global__ __launch_bounds__(256) void smm_pack_fill(int rows, int nct, int pw, int wc, const int *__restrict__ ptr, const int *__restrict__ idx,
+__global__ __launch_bounds__(256) void smm_pack_fill(int rows, int nct, int wc, const int *__restrict__ ptr, const int *__restrict__ idx,
                                                      const double *__restrict__ val, const int *__restrict__ seg,
                                                      const int2 *__restrict__ desc, double *__restrict__ pay)
 {
@@ -237,11 +247,11 @@ __global__ __launch_bounds__(256) void smm_pack_fill(int rows, int nct, int pw, 
         const int *sp = seg + (size_t)j * (nct + 1);
         for (int k = ptr[j] + lane; k < ptr[j + 1]; k += WAVE) {
             const int c = idx[k];
-            const int t = c / pw;
+            const int t = c / wc;
             const int2 d = desc[(size_t)t * rows + j];
             const int pos = k - sp[t];
             pay[d.x + pos] = val[k];
-            ((short *)(pay + d.x + d.y))[pos] = (short)(c % wc);
+            ((short *)(pay + d.x + d.y))[pos] = (short)(c - t * wc);
         }
     }
 }
@@ -729,7 +739,9 @@ struct NumericArgs {
     int64_t row_offset;
     const int *a_ptr, *a_idx; const double *a_val;
     const int *b_idx; const double *b_val;
-    const int2 *tdesc; const double *tpay; int rowsB;   // packed tile-major payload of B (smm_pack_*) for this geometry
+    const short *b_loc;             // tile-local columns (smm_loc16): the exact walk
+    const int2 *tdesc; const double *tpay; int rowsB;   // packed tile-major payload (smm_pack_*): the shared-tile walk
+    const int *seg;                 // [rowsB][n_ft+1]
     const int *dummy_idx;           // one int  = -1   (read by inactive lanes; its low half is the int16 -1)
     const double *dummy_val;        // one double
     // sparse output
@@ -771,9 +783,10 @@ __device__ __forceinline__ void smm_accumulate(const NumericArgs &A, double *__r
                                                const int thresh, const int a0, const int a1, const int ft)
 {
     const int lane = lane_id();
-    const int2 *__restrict__ desc = A.tdesc + (size_t)ft * A.rowsB;     // pieces of fine tile ft
-    const double *__restrict__ bv = A.tpay;
-    const short *__restrict__ bi = (const short *)A.tpay;
+    const size_t per = (size_t)A.n_ft + 1;
+    const int *__restrict__ segf = A.seg + ft;
+    const short *__restrict__ bi = A.b_loc;
+    const double *__restrict__ bv = A.b_val;
     const short *__restrict__ dummy_c = (const short *)A.dummy_idx;
     const unsigned long long le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);   // lanes <= this one
 
@@ -783,11 +796,10 @@ __device__ __forceinline__ void smm_accumulate(const NumericArgs &A, double *__r
         r = A.a_idx[e];
         av = A.a_val[e];
     };
-    // piece of row r: s = first 8-byte unit (values), en = s + entries; its columns are the shorts from unit en on
     auto load_seg = [&](int r, int &s, int &en) {
-        const int2 d = desc[r];
-        s = d.x;
-        en = d.x + d.y;
+        const int *sp = segf + (size_t)r * per;
+        s = sp[0];
+        en = sp[1];
     };
 
     int r_c, r_n, s_c, e_c;
@@ -807,8 +819,7 @@ __device__ __forceinline__ void smm_accumulate(const NumericArgs &A, double *__r
         const int incl = wave_scan_incl(len);
         const int first = incl - len;
         const int total = rl(incl, WAVE - 1);
-        // value of stream position g: unit .x + g; its column: short number .y + .x + g  (= 4*en + (g - first))
-        sc->tab[lane] = make_int4(s_c - first, 4 * e_c - s_c, __double2loint(a_c), __double2hiint(a_c));
+        sc->tab[lane] = make_int4(s_c - first, 0, __double2loint(a_c), __double2hiint(a_c));
         wave_sync();
         for (int g0 = 0; g0 < total; g0 += WAVE * EX_UNROLL) {
             int c[EX_UNROLL];
@@ -835,7 +846,7 @@ __device__ __forceinline__ void smm_accumulate(const NumericArgs &A, double *__r
                 const int4 t = sc->tab[j];
                 const bool p = g < total;
                 const int k = t.x + g;
-                const short *ip = p ? bi + (t.y + k) : dummy_c;
+                const short *ip = p ? bi + k : dummy_c;
                 const double *vp = p ? bv + k : A.dummy_val;
                 c[u] = *ip;
                 v[u] = *vp;
