@@ -281,8 +281,8 @@ def test_operand_cache_skips_upload_and_tile_index(smm, oracle):
         mats = [rand_csr(300, 600, 0.05, 10 + i) for i in range(3)]
         ctx.timing(True); ctx.timing_reset()
         first = smm(mats[0], B)
-        n_val, n_seg, n_loc = (ctx.kernel_time(k)[1] for k in ("smm_validate", "smm_segptr", "smm_loc16"))
-        assert n_val == 2 and n_seg >= 1                  # both operands validated, B indexed
+        n_val, n_seg, n_loc = (ctx.kernel_time(k)[1] for k in ("smm_validate", "smm_segptr", "smm_pack_fill"))
+        assert n_val == 2 and n_seg >= 1 and n_loc >= 1   # both operands validated, B indexed and packed
         for A in mats[1:]:                                # many A against one B (reference README.md:5,13)
             C = smm(A, B)
             want = oracle.sparse(arrays(A), arrays(B), 700)
@@ -290,7 +290,7 @@ def test_operand_cache_skips_upload_and_tile_index(smm, oracle):
             assert np.allclose(C.data, want[2], rtol=1e-10, atol=0)
         again = smm(mats[0], B)                           # both operands cached now
         assert np.array_equal(again.indices, first.indices) and np.allclose(again.data, first.data, rtol=1e-10, atol=0)
-        v2, s2, l2 = (ctx.kernel_time(k)[1] for k in ("smm_validate", "smm_segptr", "smm_loc16"))
+        v2, s2, l2 = (ctx.kernel_time(k)[1] for k in ("smm_validate", "smm_segptr", "smm_pack_fill"))
         assert (v2, s2, l2) == (n_val + 2, n_seg, n_loc)  # only the two new A's were validated; B untouched
         # an operand edited in place where the sample looks is seen as a new one
         B2 = B.copy(); B2.data[:] *= 2.0
