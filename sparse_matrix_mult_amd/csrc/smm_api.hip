@@ -576,7 +576,7 @@ static Geom make_geom(const smm_ctx *c, int64_t ncols, const smm_csr *b, bool ex
     // sizeof(ExactScratch) per wave behind the accumulators
     g.nw = c->waves;
     const int64_t cols = std::max<int64_t>(ncols, 1);
-    const int64_t lds_max = ((int64_t)160 * 1024 - (int64_t)g.nw * (int64_t)sizeof(ExactScratch)) / 8 - 2;
+    const int64_t lds_max = ((int64_t)160 * 1024 - (int64_t)g.nw * (int64_t)sizeof(ExactScratch) - 64 * 8) / 8 - 2;
     const int64_t wc_max = std::max<int64_t>(std::min<int64_t>(c->lds_cols, lds_max), g.nw);
     g.nct = (int)((cols + wc_max - 1) / wc_max);
     const int64_t per = (cols + g.nct - 1) / g.nct;
@@ -723,7 +723,8 @@ static int launch_numeric_t(smm_ctx *c, NumericArgs &args)
         if (args.list16) return launch_numeric_t<OUT, SYM, NW, EXACT, SCR, true>(c, args);
     }
     // accumulator tile (+ the exact walk's per-wave scratch behind it)
-    const size_t lds = (size_t)((args.wc + 1) & ~1) * sizeof(double) + (EXACT ? (size_t)NW * sizeof(ExactScratch) : 0);
+    // accumulators (+ the exact walk's per-wave scratch and the workgroup's 64-slot sink behind them)
+    const size_t lds = (size_t)((args.wc + 1) & ~1) * sizeof(double) + (EXACT ? (size_t)NW * sizeof(ExactScratch) + 64 * sizeof(double) : 0);
     auto kern = smm_numeric<OUT, SYM, NW, EXACT, SCR, L16>;
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1259,6 +1260,7 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
         A.rowlist = dense_rows;
         A.a_ptr = p->a->ptr; A.a_idx = p->a->idx; A.a_val = p->a->val;
         A.b_idx = p->b->idx; A.b_val = p->b->val; A.seg = p->seg; A.b_loc = p->loc;
+        A.kmax = (int)std::max<int64_t>(p->b->nnz - 1, 0);
         A.tdesc = p->pack.desc; A.tpay = p->pack.pay;
         A.rowsB = (int)p->b->rows;
         A.c_ptr = p->d_cptr; A.c_idx = d_c_indices; A.c_val = d_c_data;
@@ -1373,6 +1375,7 @@ static int dense_into(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t row
         A.row_offset = row_offset;
         A.a_ptr = a->ptr; A.a_idx = a->idx; A.a_val = a->val;
         A.b_idx = b->idx; A.b_val = b->val; A.seg = seg; A.b_loc = loc;
+        A.kmax = (int)std::max<int64_t>(b->nnz - 1, 0);
         A.tdesc = pack.desc; A.tpay = pack.pay;
         A.rowsB = (int)b->rows;
         A.c_dense = d_c; A.ldc = ldc;

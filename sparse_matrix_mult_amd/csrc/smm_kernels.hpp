@@ -742,6 +742,7 @@ struct NumericArgs {
     const short *b_loc;             // tile-local columns (smm_loc16): the exact walk
     const int2 *tdesc; const double *tpay; int rowsB;   // packed tile-major payload (smm_pack_*): the shared-tile walk
     const int *seg;                 // [rowsB][n_ft+1]
+    int kmax;                       // last valid position of b_loc / b_val (exact walk: lanes past a stream's end read it)
     const int *dummy_idx;           // one int  = -1   (read by inactive lanes; its low half is the int16 -1)
     const double *dummy_val;        // one double
     // sparse output
@@ -780,15 +781,15 @@ struct ExactScratch {          // per wave, in LDS behind the accumulator tile
 
 template <bool SYM>
 __device__ __forceinline__ void smm_accumulate(const NumericArgs &A, double *__restrict__ acc, ExactScratch *__restrict__ sc,
-                                               const int thresh, const int a0, const int a1, const int ft)
+                                               double *__restrict__ sink, const int thresh, const int a0, const int a1, const int ft)
 {
     const int lane = lane_id();
     const size_t per = (size_t)A.n_ft + 1;
     const int *__restrict__ segf = A.seg + ft;
     const short *__restrict__ bi = A.b_loc;
     const double *__restrict__ bv = A.b_val;
-    const short *__restrict__ dummy_c = (const short *)A.dummy_idx;
     const unsigned long long le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);   // lanes <= this one
+    const unsigned acc_a = lds_addr(acc), sink_a = lds_addr(sink) + 8u * (unsigned)lane;
 
     auto load_a = [&](int jb, int &r, double &av) {
         int e = jb + lane;
@@ -822,7 +823,7 @@ __device__ __forceinline__ void smm_accumulate(const NumericArgs &A, double *__r
         sc->tab[lane] = make_int4(s_c - first, 0, __double2loint(a_c), __double2hiint(a_c));
         wave_sync();
         for (int g0 = 0; g0 < total; g0 += WAVE * EX_UNROLL) {
-            int c[EX_UNROLL];
+            int c[EX_UNROLL], kk[EX_UNROLL];
             double v[EX_UNROLL], a[EX_UNROLL];
             // heads of this round (EX_UNROLL chunks): entries whose segment starts inside it
             wave_sync();
@@ -844,17 +845,26 @@ __device__ __forceinline__ void smm_accumulate(const NumericArgs &A, double *__r
                 if (mine == 0ull) j = carry;
                 j = j < WAVE ? j : WAVE - 1;
                 const int4 t = sc->tab[j];
-                const bool p = g < total;
-                const int k = t.x + g;
-                const short *ip = p ? bi + k : dummy_c;
-                const double *vp = p ? bv + k : A.dummy_val;
-                c[u] = *ip;
-                v[u] = *vp;
+                const int k = t.x + g;                  // positions past the end read the operand's last entry
+                kk[u] = k < A.kmax ? k : A.kmax;
                 a[u] = __hiloint2double(t.w, t.z);
             }
+            // Hand-issued loads and adds (see gload_* above): all 2 x EX_UNROLL loads back to back, then the adds
+            // in stream order.  Branch-free: a lane with nothing to add (past the end of the stream, or left of
+            // the diagonal) adds -0.0 -- neutral for every accumulator value -- into its slot of the sink.  (With
+            // `if (keep) add` the compiler sinks the value load of the round's first chunk into the branch.)
 #pragma unroll
-            for (int u = 0; u < EX_UNROLL; ++u)         // ... then add, lane order = stream order
-                if (c[u] >= thresh) lds_add(&acc[c[u]], a[u] * v[u]);
+            for (int u = 0; u < EX_UNROLL; ++u) {
+                gload_sshort(c[u], bi + kk[u]);
+                gload_f64(v[u], bv + kk[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < EX_UNROLL; ++u) {
+                wait_vm_pair(c[u], v[u], 2 * (EX_UNROLL - 1 - u));
+                const bool keep = (g0 + u * WAVE + lane) < total && c[u] >= thresh;
+                const double prod = a[u] * v[u];
+                lds_add_asm(keep ? acc_a + 8u * (unsigned)c[u] : sink_a, keep ? prod : -0.0);
+            }
         }
         wave_sync();
         s_c = s_n; e_c = e_n; a_c = a_n;
@@ -1006,7 +1016,11 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
         if (NW > 1) __syncthreads();
         SMM_LAP(t_init);
         if (!below && a1 > a0) {
-            if (EXACT) smm_accumulate<SYM>(A, acc, (ExactScratch *)(acc + ((A.wc + 1) & ~1)) + wave, thresh, a0, a1, tc * NW + wave);
+            if (EXACT) {
+                ExactScratch *scr = (ExactScratch *)(acc + ((A.wc + 1) & ~1));
+                smm_accumulate<SYM>(A, acc, scr + wave, (double *)(scr + NW), thresh, a0, a1, tc * NW + wave);
+                wait_lgkm0();                   // its hand-issued ds_add's (the compiler does not count them)
+            }
             else       smm_accumulate_shared<SYM, NW>(A, acc, lo_c, thresh, a0, a1, tc, wave);
         }
     }
