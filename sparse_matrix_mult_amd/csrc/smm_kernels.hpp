@@ -930,7 +930,7 @@ __device__ __forceinline__ void smm_accumulate_shared(const NumericArgs &A, doub
                 if (t < total && k < n) live |= 1ull << u;
                 const int a = s + k, b = 4 * (s + n) + k;          // value unit, column short; lanes past a piece's end
                 vi[u] = a < A.pmax ? a : A.pmax;                     // read the payload's last entry
-                si[u] = b < 4 * A.pmax + 3 ? b : 4 * A.pmax + 3;
+                si[u] = b < 4 * A.pmax ? b : 4 * A.pmax;
             }
             // ... all 2 x CH_UNROLL loads back to back, hand-issued (see gload_* above) ...
 #pragma unroll
