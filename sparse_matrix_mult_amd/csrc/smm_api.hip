@@ -446,7 +446,7 @@ struct smm_csr {
     struct SlabCache { int ws, n_slabs; int *soff; short *scol; double *sval; };   // slab-major copy (smm_slab.hpp)
     std::vector<SegCache> segs;
     std::vector<LocCache> locs;
-    struct PackCache { int wc, nct; int2 *desc; double *pay; int units; };   // packed tile-major payload (smm_pack_*)
+    struct PackCache { int wc, nct; int2 *desc; double *pay; };   // packed tile-major payload (smm_pack_*)
     std::vector<SlabCache> slabs;
     std::vector<PackCache> packs;
     unsigned short *idx16 = nullptr;             // 16-bit copy of idx (cols < 65535): the symbolic phase's gather stream
@@ -566,8 +566,7 @@ static Geom make_geom(const smm_ctx *c, int64_t ncols, const smm_csr *b, bool ex
         // index has one entry per coarse tile
         g.nw = c->waves_shared;
         const int64_t cols = std::max<int64_t>(ncols, 1);
-        const int64_t cap = std::min<int64_t>(c->lds_cols_shared, (160 * 1024 - 64 * 8) / 8 - 2);     // + the 64-slot sink
-        g.nct = (int)((cols + cap - 1) / cap);
+        g.nct = (int)((cols + c->lds_cols_shared - 1) / c->lds_cols_shared);
         g.wc = (int)((cols + g.nct - 1) / g.nct);
         g.wf = g.wc;
         g.n_ft = g.nct;
@@ -725,7 +724,7 @@ static int launch_numeric_t(smm_ctx *c, NumericArgs &args)
     }
     // accumulator tile (+ the exact walk's per-wave scratch behind it)
     // accumulators (+ the exact walk's per-wave scratch and the workgroup's 64-slot sink behind them)
-    const size_t lds = (size_t)((args.wc + 1) & ~1) * sizeof(double) + (EXACT ? (size_t)NW * sizeof(ExactScratch) : 0) + 64 * sizeof(double);
+    const size_t lds = (size_t)((args.wc + 1) & ~1) * sizeof(double) + (EXACT ? (size_t)NW * sizeof(ExactScratch) + 64 * sizeof(double) : 0);
     auto kern = smm_numeric<OUT, SYM, NW, EXACT, SCR, L16>;
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -789,7 +788,7 @@ struct smm_plan {
     int2 *d_tail = nullptr;        // m: where the tail of every row starts (smm_runs)
     const int *seg = nullptr;      // B's tile index and tile-local columns for geometry g (owned by b)
     const short *loc = nullptr;
-    smm_csr::PackCache pack{0, 0, nullptr, nullptr, 1};   // default mode: packed payload of B for geometry g
+    smm_csr::PackCache pack{0, 0, nullptr, nullptr};   // default mode: packed payload of B for geometry g
     bool use_slab = false;         // dense-bin rows: smm_dense_slab -> scratch -> emission, instead of the tile kernel
     SlabGeom sg{};
     smm_csr::SlabCache slab{0, 0, nullptr, nullptr, nullptr};
@@ -858,7 +857,7 @@ static int ensure_pack(smm_ctx *c, smm_csr *b, const Geom &g, smm_csr::PackCache
         if (e != hipSuccess) rc = fail(SMM_ERR_HIP, "pack build: %s", hipGetErrorString(e));
     }
     if (rc == SMM_OK && total >= INT32_MAX) rc = fail(SMM_ERR_INVALID, "operand too large for the packed payload");
-    smm_csr::PackCache e{g.wc, g.nct, nullptr, nullptr, (int)std::max<int64_t>(total, 1)};
+    smm_csr::PackCache e{g.wc, g.nct, nullptr, nullptr};
     if (rc == SMM_OK &&
         (hipMalloc((void **)&e.desc, (size_t)std::max<int64_t>(cells, 1) * sizeof(int2)) != hipSuccess ||
          hipMalloc((void **)&e.pay, (size_t)std::max<int64_t>(total, 1) * sizeof(double)) != hipSuccess)) {
@@ -1262,7 +1261,7 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
         A.a_ptr = p->a->ptr; A.a_idx = p->a->idx; A.a_val = p->a->val;
         A.b_idx = p->b->idx; A.b_val = p->b->val; A.seg = p->seg; A.b_loc = p->loc;
         A.kmax = (int)std::max<int64_t>(p->b->nnz - 1, 0);
-        A.tdesc = p->pack.desc; A.tpay = p->pack.pay; A.pmax = p->pack.units - 1;
+        A.tdesc = p->pack.desc; A.tpay = p->pack.pay;
         A.rowsB = (int)p->b->rows;
         A.c_ptr = p->d_cptr; A.c_idx = d_c_indices; A.c_val = d_c_data;
         A.ub_off = p->d_ub_off; A.tmp_idx = p->d_tmp; A.list16 = p->list16 ? 1 : 0; A.runs = p->d_runs; A.tail = p->d_tail;
@@ -1364,7 +1363,7 @@ static int dense_into(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t row
     if (!(b->vflags & CSR_UNSORTED)) {
         Geom g = make_geom(c, n, b, (flags & SMM_EXACT) != 0);
         const int *seg = nullptr; const short *loc = nullptr;
-        smm_csr::PackCache pack{0, 0, nullptr, nullptr, 1};
+        smm_csr::PackCache pack{0, 0, nullptr, nullptr};
         if (flags & SMM_EXACT) {
             CHK(ensure_seg(c, b, g, &seg));
             CHK(ensure_loc(c, b, g, &loc));
@@ -1377,7 +1376,7 @@ static int dense_into(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t row
         A.a_ptr = a->ptr; A.a_idx = a->idx; A.a_val = a->val;
         A.b_idx = b->idx; A.b_val = b->val; A.seg = seg; A.b_loc = loc;
         A.kmax = (int)std::max<int64_t>(b->nnz - 1, 0);
-        A.tdesc = pack.desc; A.tpay = pack.pay; A.pmax = pack.units - 1;
+        A.tdesc = pack.desc; A.tpay = pack.pay;
         A.rowsB = (int)b->rows;
         A.c_dense = d_c; A.ldc = ldc;
         CHK(launch_numeric<OUT_DENSE>(c, A, sym, g.nw, (flags & SMM_EXACT) != 0));

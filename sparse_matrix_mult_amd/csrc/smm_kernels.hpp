@@ -741,7 +741,6 @@ struct NumericArgs {
     const int *b_idx; const double *b_val;
     const short *b_loc;             // tile-local columns (smm_loc16): the exact walk
     const int2 *tdesc; const double *tpay; int rowsB;   // packed tile-major payload (smm_pack_*): the shared-tile walk
-    int pmax;                       // its last 8-byte unit
     const int *seg;                 // [rowsB][n_ft+1]
     int kmax;                       // last valid position of b_loc / b_val (exact walk: lanes past a stream's end read it)
     const int *dummy_idx;           // one int  = -1   (read by inactive lanes; its low half is the int16 -1)
@@ -890,14 +889,14 @@ __device__ __forceinline__ void smm_accumulate(const NumericArgs &A, double *__r
 constexpr int CH_UNROLL = SMM_CH_UNROLL;
 
 template <bool SYM, int NW>
-__device__ __forceinline__ void smm_accumulate_shared(const NumericArgs &A, double *__restrict__ acc, double *__restrict__ sink,
+__device__ __forceinline__ void smm_accumulate_shared(const NumericArgs &A, double *__restrict__ acc, const int lo_c,
                                                       const int thresh, const int a0, const int a1, const int tc,
                                                       const int wave)
 {
     const int lane = lane_id();
     const int2 *__restrict__ desc = A.tdesc + (size_t)tc * A.rowsB;
     const double *__restrict__ pay = A.tpay;
-    const unsigned acc_a = lds_addr(acc), sink_a = lds_addr(sink) + 8u * (unsigned)lane;
+    const short *__restrict__ dummy_c = (const short *)A.dummy_idx;
 
     // Wave w takes the A entries w, w+NW, ... of a round of 64*NW entries (the whole row when it
     // has <= 1024 entries): it alone loads their metadata (no NW-fold redundancy), cuts their
@@ -915,11 +914,10 @@ __device__ __forceinline__ void smm_accumulate_shared(const NumericArgs &A, doub
         const int incl = wave_scan_incl(nch);
         const int total = rl(incl, WAVE - 1);
         for (int t0 = 0; t0 < total; t0 += CH_UNROLL) {
-            int c[CH_UNROLL], own[CH_UNROLL], vi[CH_UNROLL], si[CH_UNROLL];
+            int c[CH_UNROLL], own[CH_UNROLL];
             double v[CH_UNROLL];
-            unsigned long long live = 0ull;             // bit u: this lane has an entry in chunk u
 #pragma unroll
-            for (int u = 0; u < CH_UNROLL; ++u) {       // where every chunk's lane reads ...
+            for (int u = 0; u < CH_UNROLL; ++u) {       // every load first ...
                 const int t = t0 + u;
                 int i = (int)__popcll(__ballot(incl <= t));
                 i = i < WAVE ? i : WAVE - 1;
@@ -927,25 +925,15 @@ __device__ __forceinline__ void smm_accumulate_shared(const NumericArgs &A, doub
                 const int first = rl(incl, i) - rl(nch, i);
                 const int s = rl(s_l, i), n = rl(n_l, i);
                 const int k = ((t - first) << 6) + lane;
-                if (t < total && k < n) live |= 1ull << u;
-                const int a = s + k, b = 4 * (s + n) + k;          // value unit, column short; lanes past a piece's end
-                vi[u] = a < A.pmax ? a : A.pmax;                     // read the payload's last entry
-                si[u] = b < 4 * A.pmax ? b : 4 * A.pmax;
+                const bool p = t < total && k < n;
+                const double *vp = p ? pay + s + k : A.dummy_val;
+                const short *ip = p ? (const short *)(pay + s + n) + k : dummy_c;
+                c[u] = *ip;
+                v[u] = *vp;
             }
-            // ... all 2 x CH_UNROLL loads back to back, hand-issued (see gload_* above) ...
 #pragma unroll
-            for (int u = 0; u < CH_UNROLL; ++u) {
-                gload_sshort(c[u], (const short *)pay + si[u]);
-                gload_f64(v[u], pay + vi[u]);
-            }
-            // ... then the adds, branch-free: a lane with nothing to add puts -0.0 into its slot of the sink
-#pragma unroll
-            for (int u = 0; u < CH_UNROLL; ++u) {
-                wait_vm_pair(c[u], v[u], 2 * (CH_UNROLL - 1 - u));
-                const bool keep = ((live >> u) & 1ull) && c[u] >= thresh;
-                const double prod = rl(av, own[u]) * v[u];
-                lds_add_asm(keep ? acc_a + 8u * (unsigned)c[u] : sink_a, keep ? prod : -0.0);
-            }
+            for (int u = 0; u < CH_UNROLL; ++u)         // ... then the adds
+                if (c[u] >= thresh) lds_add(&acc[c[u]], rl(av, own[u]) * v[u]);
         }
     }
 }
@@ -1033,10 +1021,7 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
                 smm_accumulate<SYM>(A, acc, scr + wave, (double *)(scr + NW), thresh, a0, a1, tc * NW + wave);
                 wait_lgkm0();                   // its hand-issued ds_add's (the compiler does not count them)
             }
-            else {
-                smm_accumulate_shared<SYM, NW>(A, acc, acc + ((A.wc + 1) & ~1), thresh, a0, a1, tc, wave);
-                wait_lgkm0();                   // its hand-issued ds_add's
-            }
+            else       smm_accumulate_shared<SYM, NW>(A, acc, lo_c, thresh, a0, a1, tc, wave);
         }
     }
     if (NW > 1) __syncthreads();
