@@ -25,8 +25,10 @@ as a child process, before this process touches the GPU).
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- algorithmic bytes of one product / duration of the numeric phase's kernels,
                   measured with HIP events on the launch stream
-  cpu_baseline -- the CPU oracle (oracle/, a port of the reference's algorithm) timed on a
-                  bounded row sample of the same operands on this box's host cores
+  cpu_baseline -- the reference's own row kernel (src/sparsework.cpp compiled by oracle/Makefile into
+                  oracle/_ref/, kind "reference") -- or, where that build is absent, the CPU oracle (a port of
+                  the reference's algorithm, kind "port") -- timed on a bounded row sample of the same
+                  operands on this box's host cores
 """
 import argparse
 import json
@@ -80,6 +82,25 @@ def cpu_baseline(torch, a, b, cols, gpu_result=None, target_s=12.0):
     out = {"value": float(cnt.sum() / dt), "unit": "nnz/s", "cores": cores, "kind": "port",
            "sample": f"first {sample} of {rows} rows of A x all of B on {cores} host threads, "
                      f"{int(cnt.sum())} output nnz in {dt:.2f} s (one thread alone: {probe / dt1 * cnt.sum() / sample:.3g} nnz/s)"}
+    # The reference's OWN row kernel (src/sparsework.cpp, unedited, built by oracle/Makefile into oracle/_ref/ with its
+    # marker initialised to -1: oracle/marker_init.c) on the same row ranges and threads, when that build travelled
+    # here: the reported baseline is then kind "reference" and the port's rate stays next to it.
+    try:
+        from oracle import ref_binding as rb
+        if rb.m1_available():
+            caps = [int(p[0].sum()) for p in parts]
+            with ThreadPoolExecutor(cores) as pool:
+                t0 = time.perf_counter()
+                rparts = list(pool.map(lambda i: rb.sparsework_once(A_, B_, rows, len(bp) - 1, cols, bounds[i], bounds[i + 1], caps[i]),
+                                       range(cores)))
+                rdt = time.perf_counter() - t0
+            same = all(np.array_equal(r[0], p[0]) and np.array_equal(r[1], p[1]) and np.array_equal(r[2], p[2])
+                       for r, p in zip(rparts, parts))
+            out.update({"value": float(cnt.sum() / rdt), "kind": "reference", "port_value": float(cnt.sum() / dt),
+                        "reference_equals_port_bit_for_bit": bool(same),
+                        "sample": out["sample"] + f"; the reference's own sparsework_nosym on the same ranges: {rdt:.2f} s"})
+    except Exception as e:                       # the checker's build is optional on the box
+        out["reference_kernel"] = f"not timed: {e!r}"
     if gpu_result is not None:
         g_ptr, g_idx, g_val = gpu_result
         nn = int(cnt.sum())

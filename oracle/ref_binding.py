@@ -135,3 +135,25 @@ def sparsework(a, b, m, k, n, row_begin, row_end, symmetric=False):
     nnz2, cnt2, idx2, val = run(nnz)
     assert nnz2 == nnz and np.array_equal(idx, idx2) and np.array_equal(cnt, cnt2)
     return cnt, idx, val
+
+
+def sparsework_once(a, b, m, k, n, row_begin, row_end, capacity, symmetric=False):
+    """ONE run of the reference's row kernel (as in sparsework() above) with the initial capacity given -- the
+    exact nnz of the rows, so that HEAD's pool never grows and `values` come back intact.  This is the call
+    bench.py times as cpu_baseline kind "reference" (several row ranges on several host threads: ctypes
+    releases the GIL and the kernel keeps no global state)."""
+    global _LIB_M1
+    if _LIB_M1 is None:
+        sparsework(a, b, m, k, n, row_begin, min(row_begin + 1, row_end), symmetric)      # loads the library
+    fn = _LIB_M1.sparsework_sym if symmetric else _LIB_M1.sparsework_nosym
+    libc = ctypes.CDLL(None)
+    libc.free.argtypes = [ctypes.c_void_p]
+    nr = row_end - row_begin
+    sa, sb, out = _wrap(a, m, k), _wrap(b, k, n), SparseMatSz()
+    fn(ctypes.byref(sa), ctypes.byref(sb), ctypes.byref(out), row_begin, row_end - 1, int(max(capacity, 1)))
+    nnz = int(out.nzmax)
+    cnt = np.ctypeslib.as_array(out.rowPtr, shape=(nr,)).copy().astype(np.int64)
+    idx = np.ctypeslib.as_array(out.colInd, shape=(max(nnz, 1),))[:nnz].copy()
+    val = np.ctypeslib.as_array(out.values, shape=(max(nnz, 1),))[:nnz].copy()
+    libc.free(ctypes.cast(out.rowPtr, ctypes.c_void_p))
+    return cnt, idx, val
