@@ -326,3 +326,32 @@ def test_wide_index_result_is_a_usable_scipy_matrix(ctx, oracle):
     want = oracle.dense(arrays(A), arrays(B), 500)
     x = np.random.default_rng(3).random(500)
     assert np.allclose(C @ x, want @ x) and np.array_equal(C.toarray(), want) and np.array_equal(C[10:20].toarray(), want[10:20])
+
+
+def test_large_result_takes_the_pipelined_download(ctx, oracle):
+    """Results >= 256 MB come back through the ring of pinned buffers + host copy threads (smm_api.hip: download()):
+    a 6200 x 6200 dense result (307 MB) and a CSR result whose value array alone is > 256 MB, against the same
+    products left on the device and fetched with plain copies."""
+    import torch
+    n = 6200
+    A, B = rand_csr(n, 500, 0.02, 51), rand_csr(500, n, 0.02, 52)
+    a, b = ctx.csr_from_scipy(A), ctx.csr_from_scipy(B)
+    try:
+        got = ctx.dense_host(a, b, exact=True)
+        dev = torch.empty((n, n), dtype=torch.float64, device=torch.device("cuda", ctx.device))
+        ctx.dense_into(a, b, dev.data_ptr(), exact=True)
+        ctx.synchronize()
+        assert got.nbytes >= 256 << 20 and np.array_equal(got, dev.cpu().numpy())
+        want = oracle.dense(arrays(A), arrays(B), n, row_begin=3000, row_end=3040)
+        assert np.array_equal(got[3000:3040], want)
+    finally:
+        a.close(); b.close()
+    A2, B2 = rand_csr(n, 2000, 0.04, 53), rand_csr(2000, n, 0.04, 54)       # 3.2 products per cell: C is 96 % full
+    a, b = ctx.csr_from_scipy(A2), ctx.csr_from_scipy(B2)
+    try:
+        ptr, idx, val = ctx.spgemm_host(a, b, exact=True)
+        dp, di, dv = ctx.spgemm_torch(a, b, exact=True)
+        assert val.nbytes >= 256 << 20
+        assert np.array_equal(ptr, dp.cpu().numpy()) and np.array_equal(idx, di.cpu().numpy()) and np.array_equal(val, dv.cpu().numpy())
+    finally:
+        a.close(); b.close()
