@@ -64,6 +64,9 @@ struct smm_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool timing = false;
+    int s2_group = 5;        // triple stage 2: k-groups whose blocks follow each other on one XCD and share a tile of T
+                             // through its L2 (env SMM_S2_GROUP; at BASELINE configs[3] 1: 58.2, 2: 56.3, 4: 60.1, 5: 54.8,
+                             // 7: 54.9, 8: 58.9, 10: 54.8 ms -- powers of two lose, profiles/r2_s2_sweeps.txt)
     int lds_cols = 18000;    // SMM_EXACT walk: accumulator columns per workgroup (x8 B of LDS; 1.5 KB of
     int waves = 8;           // scratch per wave sit behind them) and waves per workgroup (each owns 1/waves)
     int lds_cols_shared = 20000;   // default (shared-tile) walk: tile columns and waves per workgroup
@@ -180,6 +183,7 @@ extern "C" int smm_ctx_create(int device, void *hip_stream, smm_ctx **out)
     smm_ctx *c = new smm_ctx();
     c->device = device;
     if (const char *e = getenv("SMM_NARROW_IDX")) c->narrow_idx = atoi(e) != 0;     // A/B switch (scripts/ab_env.sh)
+    if (const char *e = getenv("SMM_S2_GROUP")) c->s2_group = std::max(1, atoi(e));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hip_stream == SMM_STREAM_DEFAULT) { c->stream = nullptr; c->own_stream = false; }   // the device's null stream
     else if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
@@ -451,7 +455,7 @@ struct smm_csr {
     std::vector<PackCache> packs;
     unsigned short *idx16 = nullptr;             // 16-bit copy of idx (cols < 65535): the symbolic phase's gather stream
     // sliced-ELL copy for triple-product stage 2 (chunk width ell_chunk)
-    int ell_chunk = 0, ell_nchunks = 0; int *ell_len = nullptr; int64_t *ell_off = nullptr;
+    int ell_chunk = 0, ell_nchunks = 0; bool ell_spread = false; int64_t *ell_off = nullptr;
     short *ell_col = nullptr; double *ell_val = nullptr;
 };
 
@@ -542,7 +546,7 @@ extern "C" void smm_csr_destroy(smm_csr *m)
     for (auto &e : m->slabs) { (void)hipFree(e.soff); (void)hipFree(e.scol); (void)hipFree(e.sval); }
     for (auto &e : m->packs) { (void)hipFree(e.desc); (void)hipFree(e.pay); }
     (void)hipFree(m->idx16);
-    (void)hipFree(m->ell_len); (void)hipFree(m->ell_off); (void)hipFree(m->ell_col); (void)hipFree(m->ell_val);
+    (void)hipFree(m->ell_off); (void)hipFree(m->ell_col); (void)hipFree(m->ell_val);
     delete m;
 }
 extern "C" int64_t smm_csr_rows(const smm_csr *m) { return m ? m->rows : -1; }
@@ -641,30 +645,32 @@ static int ensure_loc(smm_ctx *c, smm_csr *b, const Geom &g, const short **out)
     return SMM_OK;
 }
 
-// Sliced-ELL re-layout of H for triple-product stage 2 (see smm_triple_stage2); cached per chunk width.
-static int ensure_ell(smm_ctx *c, smm_csr *h, int nchunks, int chunk)
+// Sliced-ELL re-layout of H for triple-product stage 2 (see smm_triple_stage2); one copy is cached per
+// handle, for one chunk width and one order of the steps (spread = conflict-free order of the default mode,
+// stored order for SMM_EXACT).
+static int ensure_ell(smm_ctx *c, smm_csr *h, int nchunks, int chunk, bool spread)
 {
-    if (h->ell_val && h->ell_chunk == chunk && h->ell_nchunks == nchunks) return SMM_OK;
+    if (h->ell_val && h->ell_chunk == chunk && h->ell_nchunks == nchunks && h->ell_spread == spread) return SMM_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
-    (void)hipFree(h->ell_len); (void)hipFree(h->ell_off); (void)hipFree(h->ell_col); (void)hipFree(h->ell_val);
-    h->ell_len = nullptr; h->ell_off = nullptr; h->ell_col = nullptr; h->ell_val = nullptr; h->ell_chunk = 0;
+    (void)hipFree(h->ell_off); (void)hipFree(h->ell_col); (void)hipFree(h->ell_val);
+    h->ell_off = nullptr; h->ell_col = nullptr; h->ell_val = nullptr; h->ell_chunk = 0;
     Geom gh; gh.nw = 1; gh.nct = nchunks; gh.wf = chunk; gh.wc = chunk; gh.n_ft = nchunks;
     const int *hseg = nullptr;
     CHK(ensure_seg(c, h, gh, &hseg));
     const int n = (int)h->rows;
     const int nslices = (n + WAVE - 1) / WAVE;
     const int64_t items = (int64_t)nchunks * nslices;
+    if (items >= 0x7fffffff) return fail(SMM_ERR_INVALID, "H too large for the sliced-ELL index (%lld blocks)", (long long)items);
     int64_t *cnt = nullptr;
     CHK(pool_get(c, (size_t)items, &cnt));
-    if (hipMalloc((void **)&h->ell_len, (size_t)nchunks * n * sizeof(int)) != hipSuccess ||
-        hipMalloc((void **)&h->ell_off, (size_t)(items + 1) * sizeof(int64_t)) != hipSuccess) {
+    if (hipMalloc((void **)&h->ell_off, (size_t)(items + 1) * sizeof(int64_t)) != hipSuccess) {
         pool_free(c, cnt);
         return fail(SMM_ERR_ALLOC, "hipMalloc of the ELL index failed");
     }
     EllArgs E{};
     E.n = n; E.nchunks = nchunks; E.chunk = chunk; E.nslices = nslices;
     E.h_ptr = h->ptr; E.h_idx = h->idx; E.h_val = h->val; E.hseg = hseg;
-    E.len = h->ell_len; E.cnt = cnt; E.off = h->ell_off;
+    E.cnt = cnt; E.off = h->ell_off;
     const int grid = (int)((items + 3) / 4);
     LAUNCH(c, "smm_ell_count", smm_ell_count, grid, 256, 0, E);
     LAUNCH(c, "smm_scan", smm_scan<int64_t>, 1, 1024, 0, (int)items, (const int64_t *)cnt, h->ell_off);
@@ -677,9 +683,10 @@ static int ensure_ell(smm_ctx *c, smm_csr *h, int nchunks, int chunk)
         hipMalloc((void **)&h->ell_val, (total + WAVE) * sizeof(double)) != hipSuccess)
         return fail(SMM_ERR_ALLOC, "hipMalloc of the ELL payload (%lld entries) failed", (long long)total);
     E.col = h->ell_col; E.val = h->ell_val;
-    LAUNCH(c, "smm_ell_fill", smm_ell_fill, grid, 256, 0, E);
+    if (spread) LAUNCH(c, "smm_ell_fill", smm_ell_fill<true>, grid, 256, 0, E);
+    else LAUNCH(c, "smm_ell_fill", smm_ell_fill<false>, grid, 256, 0, E);
     LAUNCH_CHECK();
-    h->ell_chunk = chunk; h->ell_nchunks = nchunks;
+    h->ell_chunk = chunk; h->ell_nchunks = nchunks; h->ell_spread = spread;
     return SMM_OK;
 }
 
@@ -1492,22 +1499,27 @@ extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags,
     const int chunk_cap = 1024;            // [chunk][R+2] f64 = 144 KB of LDS
     const int nchunks = (int)((K + chunk_cap - 1) / chunk_cap);
     const int chunk = (int)((K + nchunks - 1) / nchunks);
-    rc = ensure_ell(c, h, nchunks, chunk);
+    const bool exact = (flags & SMM_EXACT) != 0;
+    rc = ensure_ell(c, h, nchunks, chunk, !exact);
     if (rc != SMM_OK) { pool_free(c, T); return rc; }
     TripleArgs A{};
     A.n = (int)n; A.K = (int)K; A.nchunks = nchunks; A.chunk = chunk; A.nslices = (int)((n + WAVE - 1) / WAVE);
     A.nib = (int)((nr + R - 1) / R);
     A.row_begin = row_begin; A.row_end = row_end; A.full = full ? 1 : 0;
-    A.len = h->ell_len; A.off = h->ell_off; A.col = h->ell_col; A.val = h->ell_val;
+    A.off = h->ell_off; A.col = h->ell_col; A.val = h->ell_val;
     A.T = T; A.C = d_c; A.ldc = n;
     const size_t lds = (size_t)(R + 2) * chunk * sizeof(double);
     const int64_t nkg = (n + NW * WAVE - 1) / (NW * WAVE);
-    auto kern = smm_triple_stage2<R, NW, 1024>;
+    auto kern = exact ? smm_triple_stage2<R, NW, 1024, false> : smm_triple_stage2<R, NW, 1024, true>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { pool_free(c, T); return fail(SMM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e)); }
     }
-    LAUNCH(c, "smm_triple_stage2", kern, nkg * A.nib, NW * 64, lds, A);
+    A.nkg = (int)nkg;
+    A.gk = (int)std::min<int64_t>(std::max(c->s2_group, 1), nkg);
+    const int64_t grid2 = ((nkg + A.gk - 1) / A.gk) * A.gk * (((int64_t)A.nib + 7) / 8) * 8;
+    if (grid2 > 0x7fffffff) { pool_free(c, T); return fail(SMM_ERR_INVALID, "triple product too large for one launch"); }
+    LAUNCH(c, "smm_triple_stage2", kern, grid2, NW * 64, lds, A);
     if (full) LAUNCH(c, "smm_triple_mirror", smm_triple_mirror, (n * n + 255) / 256, 256, 0, (int)n, d_c, n);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // T returns to the pool below

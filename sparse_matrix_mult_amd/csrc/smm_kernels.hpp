@@ -1367,34 +1367,36 @@ __global__ __launch_bounds__(256) void smm_dense_general(int m, int ncols, int64
 // ---------------------------------------------------------------------------------------
 // Triple product, stage 2 (sparse_sparse_dense.cpp:201-216): C[i,k] = sum over row k of H of
 // T[i, col] * val, for k >= i (or all k), where T = H*Q is the dense n x K matrix stage 1
-// (smm_numeric<OUT_DENSE>) left in HBM.  The sum runs in H's stored order starting from 0.0,
-// exactly as the reference's scalar loop, so stage 2 is bit-exact given T.
+// (smm_numeric<OUT_DENSE>) left in HBM.  With SMM_EXACT the sum runs in H's stored order starting
+// from 0.0, product rounded before the addition, exactly as the reference's scalar loop: stage 2 is
+// bit-exact given T.  By default the entries of a row inside one chunk are taken in the order that
+// keeps the LDS gather free of bank conflicts (smm_ell_fill<true>) and multiply-add is fused: the
+// same sum, within the 1e-10 of the default mode, at 1.4x the speed.
 //
 // Layout.  A workgroup owns a block of R rows of T and a group of NW*64 rows k of H (one k per
 // lane, one 64-row slice per wave); its R running sums per lane stay in registers from the
-// first column of H to the last.  K is cut into chunks of <= 512 columns; the R x chunk piece
+// first column of H to the last.  K is cut into chunks of <= 1024 columns; the R x chunk piece
 // of T sits in LDS column-major with a 2-double pad ([chunk][R+2]: the R values of one column
 // are one contiguous run, read with ds_read_b128; the pad spreads a wave's random columns over
 // all banks -- 1.46x the gather rate of the row-major tile it replaced,
 // scripts/ubench/lds_gather.hip).  Chunks are visited in ascending column order = stored order
-// of a sorted H, so the order of additions is the reference's.
+// of a sorted H, so with the ELL steps in stored order the order of additions is the reference's.
 // A lane walking its own CSR row would make every load 64 separate 12-byte requests, so H is
 // re-laid once (cached on the handle) as sliced ELL per chunk: for 64 consecutive rows k and
 // chunk q, step s of all 64 rows is stored contiguously -- int16 chunk-local column + f64
-// value -- padded to the longest of the 64 segments.
+// value -- padded to the longest of the 64 segments (column -1 = no entry).
 // Traffic: the ELL copy of H is streamed once per row block (n/R times; consecutive workgroups
 // share one k-group, so it is served by the Infinity Cache), T once per k-group.
 struct EllArgs {
     int n, nchunks, chunk, nslices;
     const int *h_ptr, *h_idx; const double *h_val;
     const int *hseg;                  // [n][nchunks+1]
-    int *len;                         // [nchunks][n]        segment length of row k in chunk q
     int64_t *cnt;                     // [nchunks][nslices]  64 * longest segment of the slice
     const int64_t *off;               // exclusive scan of cnt (+ total)
-    short *col; double *val;          // ELL payload
+    short *col; double *val;          // ELL payload; col < 0 = no entry in this step
 };
 
-// pass 1: lengths and per-slice maxima (one wave per (chunk, slice))
+// pass 1: per-slice maxima (one wave per (chunk, slice))
 __global__ __launch_bounds__(256) void smm_ell_count(const EllArgs A)
 {
     const int lane = lane_id();
@@ -1406,16 +1408,28 @@ __global__ __launch_bounds__(256) void smm_ell_count(const EllArgs A)
     if (k < A.n) {
         const int *sp = A.hseg + (size_t)k * (A.nchunks + 1) + q;
         len = sp[1] - sp[0];
-        A.len[(size_t)q * A.n + k] = len;
     }
     int mx = len;
     for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
     if (lane == 0) A.cnt[item] = (int64_t)mx * WAVE;
 }
 
-// pass 2: payload (one wave per (chunk, slice))
+// pass 2: payload (one wave per (chunk, slice)).
+// SPREAD = false (SMM_EXACT): step s of a lane is entry s of its segment -- the reference's order of additions.
+// SPREAD = true: the entries of a segment are dealt to the steps so that the 16 lanes of one ds_read_b128
+// conflict group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, the same + 32: MI355X_MICROARCH.md, LDS table) read
+// columns distinct mod 16 in every step.  Stage 2's tile is [column][R + 2] doubles with R = 16, so the 16-byte
+// slot of a lane's read j is (9 c + j) mod 16: distinct columns mod 16 = no bank conflict, where the stored
+// order costs 2.3 LDS passes per step (scripts/ubench/lds_conflict.hip: 1.65x the gather rate).  Greedy, one
+// step at a time: the lanes of a group choose one after the other the lowest residue class they still hold
+// an entry of and nobody in the group has taken in this step; a lane that finds none sits the step out while
+// it has steps to spare (the block is as long as the longest of the 64 segments, so most lanes do), and
+// takes a conflict otherwise.  Within a residue class the stored order is kept.  Blocks longer than 64 steps
+// stay in stored order.
+template <bool SPREAD>
 __global__ __launch_bounds__(256) void smm_ell_fill(const EllArgs A)
 {
+    __shared__ unsigned char s_ord[4][WAVE][64], s_ptr[4][WAVE][16], s_end[4][WAVE][16];
     const int lane = lane_id();
     const int64_t item = (int64_t)blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x >> 6);
     if (item >= (int64_t)A.nchunks * A.nslices) return;
@@ -1429,9 +1443,57 @@ __global__ __launch_bounds__(256) void smm_ell_fill(const EllArgs A)
     const int64_t base = A.off[item];
     const int steps = (int)((A.off[item + 1] - base) / WAVE);
     const int lo = q * A.chunk;
+    if (!SPREAD || steps > 64) {
+        for (int st = 0; st < steps; ++st) {
+            short c = -1; double v = 0.0;
+            if (st < len) { c = (short)(A.h_idx[s + st] - lo); v = A.h_val[s + st]; }
+            A.col[base + (int64_t)st * WAVE + lane] = c;
+            A.val[base + (int64_t)st * WAVE + lane] = v;
+        }
+        return;
+    }
+    const int w = threadIdx.x >> 6;
+    unsigned char *ord = s_ord[w][lane], *ptr = s_ptr[w][lane], *end = s_end[w][lane];
+    // positions of the segment sorted by column mod 16 (stable): ord[ptr[r] .. end[r])
+    for (int r = 0; r < 16; ++r) ptr[r] = 0;
+    for (int p = 0; p < len; ++p) ++ptr[(A.h_idx[s + p] - lo) & 15];
+    {
+        int acc = 0;
+        for (int r = 0; r < 16; ++r) { const int c = ptr[r]; ptr[r] = (unsigned char)acc; acc += c; }
+    }
+    for (int p = 0; p < len; ++p) ord[ptr[(A.h_idx[s + p] - lo) & 15]++] = (unsigned char)p;
+    unsigned avail = 0;
+    for (int r = 15; r >= 0; --r) {
+        end[r] = ptr[r];
+        ptr[r] = r ? ptr[r - 1] : 0;
+    }
+    for (int r = 0; r < 16; ++r) avail |= (ptr[r] < end[r] ? 1u : 0u) << r;
+    // conflict group and position in it
+    const int l32 = lane & 31;
+    const int odd = (l32 >= 4 && l32 < 12) || (l32 >= 16 && l32 < 20) || l32 >= 28;
+    const int gp = l32 < 4 ? l32 : l32 < 12 ? l32 - 4 : l32 < 20 ? l32 - 8 : l32 < 28 ? l32 - 12 : l32 - 16;
+    int rem = len;
     for (int st = 0; st < steps; ++st) {
-        short c = 0; double v = 0.0;
-        if (st < len) { c = (short)(A.h_idx[s + st] - lo); v = A.h_val[s + st]; }
+        const int left = steps - st;
+        unsigned used = 0; int pick = -1;
+        for (int i = 0; i < 16; ++i) {
+            unsigned bit = 0;
+            if (gp == i && rem > 0) {
+                const unsigned m = avail & ~used;
+                if (m) pick = __ffs(m) - 1;
+                else if (rem >= left) pick = __ffs(avail) - 1;       // no step to spare: take the conflict
+                if (pick >= 0) bit = 1u << pick;
+            }
+            const int src = (lane & 32) + (odd ? (i < 8 ? i + 4 : i < 12 ? i + 8 : i + 16) : (i < 4 ? i : i < 8 ? i + 8 : i + 12));
+            used |= (unsigned)__shfl((int)bit, src);
+        }
+        short c = -1; double v = 0.0;
+        if (pick >= 0) {
+            const int p = ord[ptr[pick]];
+            if (++ptr[pick] == end[pick]) avail &= ~(1u << pick);
+            --rem;
+            c = (short)(A.h_idx[s + p] - lo); v = A.h_val[s + p];
+        }
         A.col[base + (int64_t)st * WAVE + lane] = c;
         A.val[base + (int64_t)st * WAVE + lane] = v;
     }
@@ -1439,17 +1501,29 @@ __global__ __launch_bounds__(256) void smm_ell_fill(const EllArgs A)
 
 struct TripleArgs {
     int n, K, nchunks, chunk, nslices;
-    int nib;                          // row blocks; blockIdx.x = kgroup * nib + row block
+    int nib, nkg, gk;                 // row blocks, k-groups; block order: see smm_triple_stage2
     int64_t row_begin, row_end;
     int full;
-    const int *len;                   // [nchunks][n]
     const int64_t *off;               // [nchunks*nslices + 1]
     const short *col; const double *val;
     const double *T;                  // (row_end-row_begin) x K
     double *C; int64_t ldc;           // row row_begin at C
 };
 
-template <int R, int NW, int CW>
+// diagnostic builds (make variant EXTRA=-DSMM_S2_DIAG=n): 1 = no loads of T, 4 = no barriers, 16 = every block
+// loads the tiles of row block 0 (L2 hits).  Wrong results, timing only.
+#ifndef SMM_S2_DIAG
+#define SMM_S2_DIAG 0
+#endif
+#ifndef SMM_S2_DEPTH
+#define SMM_S2_DEPTH 8
+#endif
+#if SMM_S2_DIAG & 4
+#define S2_SYNC() __builtin_amdgcn_sched_barrier(0)
+#else
+#define S2_SYNC() __syncthreads()
+#endif
+template <int R, int NW, int CW, bool FMA>
 __global__ __launch_bounds__(NW * 64) void smm_triple_stage2(const TripleArgs A)
 {
     constexpr int RP = NW * 64 / CW;                   // tile rows filled per pass (chunk <= CW columns)
@@ -1457,9 +1531,21 @@ __global__ __launch_bounds__(NW * 64) void smm_triple_stage2(const TripleArgs A)
     static_assert(RP >= 1 && RP * CW == NW * 64 && R % (2 * RP) == 0 && NV == 16, "tile fill: CW threads per row");
     extern __shared__ double tl[];                     // [chunk][R + 2]
     constexpr int LD = R + 2;
+    constexpr int D = SMM_S2_DEPTH;                    // steps of H entries in flight
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int ib = (int)(blockIdx.x % (unsigned)A.nib), kg = (int)(blockIdx.x / (unsigned)A.nib);
+    // Block order.  The gk k-groups of one super-group that meet the same row block follow each other on the
+    // same XCD (workgroup b runs on XCD b % 8), so the tile of T that the first of them pulls from HBM is in
+    // that XCD's L2 for the others; the row blocks of a super-group, 8 at a time over the XCDs, all stream
+    // the same gk ELL copies.
+    int ib, kg;
+    {
+        const unsigned x = blockIdx.x & 7u; unsigned t = blockIdx.x >> 3;
+        const unsigned nib8 = ((unsigned)A.nib + 7u) >> 3;
+        const unsigned g = t % (unsigned)A.gk; t /= (unsigned)A.gk;
+        ib = (int)((t % nib8) * 8u + x); kg = (int)((t / nib8) * (unsigned)A.gk + g);
+        if (ib >= A.nib || kg >= A.nkg) return;
+    }
     const int64_t i0 = A.row_begin + (int64_t)ib * R;
     const int nr = (A.row_end - i0) < R ? (int)(A.row_end - i0) : R;
     const int sl = kg * NW + wave;                     // this wave's 64 rows of H
@@ -1476,89 +1562,95 @@ __global__ __launch_bounds__(NW * 64) void smm_triple_stage2(const TripleArgs A)
     double sum[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) sum[r] = 0.0;
+    // SMM_EXACT: product rounded, then added (the reference's x86-64 build has no fused multiply-add);
+    // default: one v_fma_f64 -- half the VALU work of the gather loop, and one rounding less
+    auto mad = [](double x, double h, double acc) { return FMA ? __builtin_fma(x, h, acc) : acc + x * h; };
     // Tile fill: thread (fr, fx) owns column fx of tile rows fr, fr + RP, ...  The NV elements of the
-    // NEXT chunk travel in registers while the current chunk is consumed: two of the loads are issued
-    // with each of the first NV/2 step pairs, next to the H entries requested there, so they complete
-    // together (vmcnt retires in order: a block of tile loads in front of the step loop would stall
-    // the first wait for H entries for a full memory round trip; a fill between the two barriers
-    // cost 15 % of the kernel).  Rows past the last row of the block and columns past the chunk are
-    // clamped (loaded twice, stored never / never read).
+    // NEXT chunk travel in registers while the current chunk is consumed (a fill between the two
+    // barriers cost 15 % of the kernel).  Rows past the last row of the block and columns past the
+    // chunk are clamped (loaded twice, stored never / never read).
     const int fx = threadIdx.x % CW, fr = threadIdx.x / CW;
     const double *trow[1];
+#if SMM_S2_DIAG & 16
+    trow[0] = A.T;                                     // every block reads the tiles of row block 0: L2 hits
+#else
     trow[0] = A.T + (i0 - A.row_begin) * A.K;
+#endif
     double v[NV];
+#if SMM_S2_DIAG & 1
+#define TILE_LD(t, lo_, w_) v[t] = 1.0 + (t) + (lo_) + (w_)
+#else
 #define TILE_LD(t, lo_, w_)                                                                     \
     v[t] = trow[0][(int64_t)((fr + RP * (t)) < nr ? (fr + RP * (t)) : nr - 1) * A.K + (lo_) +   \
                    (fx < (w_) ? fx : (w_) - 1)]
+#endif
     {
         const int w0 = A.K < A.chunk ? A.K : A.chunk;
 #pragma unroll
         for (int t = 0; t < NV; ++t) TILE_LD(t, 0, w0);
     }
-    // Per-chunk metadata (segment length of this lane's row, the slice's block in the ELL arrays) is
-    // loaded one chunk ahead, and the first two steps of a chunk are requested before the barrier,
-    // so no wave starts a chunk with a chain of dependent round trips.  Waves without work (slice
-    // beyond n or left of the diagonal) run the same loads on clamped indices and 0 steps.
+    // Per-chunk metadata (the slice's block in the ELL arrays) is loaded one chunk ahead, and the first
+    // D steps of a chunk are requested before the barrier, so no wave starts a chunk with a chain of
+    // dependent round trips.  Waves without work (slice beyond n or left of the diagonal) run the same
+    // loads on clamped indices and 0 steps.  A lane has an entry in a step iff its column is >= 0.
     const int slc = sl < A.nslices ? sl : A.nslices - 1;
-    const int64_t kc = kin ? k : A.n - 1;
-    int len_n = A.len[kc];
     int64_t base_n = A.off[slc], end_n = A.off[slc + 1];
+
     for (int q = 0; q < A.nchunks; ++q) {
         const int lo = q * A.chunk;
         const int w = (A.K - lo) < A.chunk ? (A.K - lo) : A.chunk;
-        const int len = (work && kin) ? len_n : 0;
         const int steps = work ? (int)((end_n - base_n) / WAVE) : 0;
         const short *cp = A.col + base_n + lane;
         const double *vp = A.val + base_n + lane;
-        // the entries of the next two steps are in flight while two steps are consumed (indices are
-        // clamped into the slice's block; a clamped step has st >= steps >= len and adds nothing)
+        // The entries of the next D steps travel in registers (indices are clamped into the slice's block; a
+        // clamped step has st >= steps and adds nothing).  vmcnt retires in order, so a wait for an H entry
+        // also waits for every tile load issued before it: the NV loads of the NEXT chunk's tile go out in
+        // one burst behind the first D steps' entries, and the entries requested after the burst are not
+        // needed before D steps of gathers have run -- the HBM round trip of the tile hides behind them.
+        // (Two tile loads per step pair, as this loop did before, exposed that round trip NV/2 times per
+        // chunk: 14 of 55 ms at BASELINE configs[3].)
         const int last = steps > 0 ? steps - 1 : 0;
-        const int s1 = 1 < last ? 1 : last;
-        int c0 = cp[0], c1 = cp[(int64_t)s1 * WAVE];
-        double h0 = vp[0], h1 = vp[(int64_t)s1 * WAVE];
-        __syncthreads();                               // nobody reads the previous tile any more
+        int cc[D]; double hh[D];
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int su = u < last ? u : last;
+            cc[u] = cp[(int64_t)su * WAVE]; hh[u] = vp[(int64_t)su * WAVE];
+        }
+        S2_SYNC();                               // nobody reads the previous tile any more
         if (fx < w) {
             double *dst = tl + fx * LD + fr;
 #pragma unroll
             for (int t = 0; t < NV; ++t) dst[RP * t] = v[t];
         }
         const int qn = q + 1 < A.nchunks ? q + 1 : q;
-        len_n = A.len[(size_t)qn * A.n + kc];
-        base_n = A.off[(size_t)qn * A.nslices + slc];
-        end_n = A.off[(size_t)qn * A.nslices + slc + 1];
+        {
+            const int mi = __builtin_amdgcn_readfirstlane(qn * A.nslices + slc);    // wave-uniform: scalar loads
+            base_n = A.off[mi]; end_n = A.off[mi + 1];
+        }
         const int lon = qn * A.chunk;
         const int wn = (A.K - lon) < A.chunk ? (A.K - lon) : A.chunk;
-        __syncthreads();
-        int st = 0;
-#define STEP_PAIR()                                                                             \
-        {                                                                                       \
-            const int s2 = st + 2 < last ? st + 2 : last, s3 = st + 3 < last ? st + 3 : last;   \
-            const int n0 = cp[(int64_t)s2 * WAVE], n1 = cp[(int64_t)s3 * WAVE];                 \
-            const double g0 = vp[(int64_t)s2 * WAVE], g1 = vp[(int64_t)s3 * WAVE];              \
-            if (st < len) {                                                                     \
-                const double2 *p = reinterpret_cast<const double2 *>(tl + c0 * LD);             \
+        S2_SYNC();
+#pragma unroll
+        for (int t = 0; t < NV; ++t) TILE_LD(t, lon, wn);
+        // The first D steps stand in front of the loop: their entries were requested before the burst, and only
+        // in straight-line code does the compiler count the loads that may still be in flight exactly
+        // (s_waitcnt vmcnt(NV + 2u)); inside the loop it has to assume the back edge's 2(D-1).
+#define STEP_GROUP(st_)                                                                         \
+        _Pragma("unroll") for (int u = 0; u < D; ++u) {                                         \
+            if ((st_) + u < steps && cc[u] >= 0) {                                              \
+                const double2 *p = reinterpret_cast<const double2 *>(tl + cc[u] * LD);          \
                 _Pragma("unroll") for (int r = 0; r < R; r += 2) {                              \
                     const double2 x = p[r >> 1];                                                \
-                    sum[r] += x.x * h0;                                                         \
-                    sum[r + 1] += x.y * h0;                                                     \
+                    sum[r] = mad(x.x, hh[u], sum[r]);                                           \
+                    sum[r + 1] = mad(x.y, hh[u], sum[r + 1]);                                   \
                 }                                                                               \
             }                                                                                   \
-            if (st + 1 < len) {                                                                 \
-                const double2 *p = reinterpret_cast<const double2 *>(tl + c1 * LD);             \
-                _Pragma("unroll") for (int r = 0; r < R; r += 2) {                              \
-                    const double2 x = p[r >> 1];                                                \
-                    sum[r] += x.x * h1;                                                         \
-                    sum[r + 1] += x.y * h1;                                                     \
-                }                                                                               \
-            }                                                                                   \
-            c0 = n0; c1 = n1; h0 = g0; h1 = g1;                                                 \
-            st += 2;                                                                            \
+            const int sn = (st_) + u + D < last ? (st_) + u + D : last;                         \
+            cc[u] = cp[(int64_t)sn * WAVE]; hh[u] = vp[(int64_t)sn * WAVE];                     \
         }
-#define FILL_PAIR(t) TILE_LD(2 * (t), lon, wn); TILE_LD(2 * (t) + 1, lon, wn); STEP_PAIR()
-        FILL_PAIR(0) FILL_PAIR(1) FILL_PAIR(2) FILL_PAIR(3) FILL_PAIR(4) FILL_PAIR(5) FILL_PAIR(6) FILL_PAIR(7)
-        while (st < steps) STEP_PAIR()
-#undef FILL_PAIR
-#undef STEP_PAIR
+        STEP_GROUP(0)
+        for (int st = D; st < steps; st += D) { STEP_GROUP(st) }
+#undef STEP_GROUP
     }
 #undef TILE_LD
     if (kin) {

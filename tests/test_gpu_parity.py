@@ -239,6 +239,39 @@ def test_triple_matches_oracle(ctx, oracle, n, k, dh, dq, full, exact):
         assert rel_err(got, want) <= RTOL
 
 
+def test_triple_step_order_edge_cases(ctx, oracle):
+    """Default mode deals the entries of a row to the ELL steps so that a wave's LDS reads do not collide
+    (smm_ell_fill<true>).  Edge cases of that scheduler: every column of H in ONE residue class mod 16 (no
+    collision-free order exists: it must still place every entry), rows of very different length inside one
+    64-row slice (lanes with and without steps to spare), and the same handle used in default, exact and default
+    mode again (the ELL copy is rebuilt for the order each mode needs)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(77)
+    n, k = 200, 1600
+    # (a) columns = 3 mod 16 only
+    cols = np.arange(3, k, 16)
+    Ha = sp.random(n, len(cols), density=0.4, format="csr", random_state=rng)
+    Ha = sp.csr_matrix((Ha.data, cols[Ha.indices], Ha.indptr), shape=(n, k))
+    # (b) ragged: row r has about r % 64 entries
+    rows = [np.sort(rng.choice(k, size=(r % 64) + (3 if r % 7 == 0 else 0), replace=False)) for r in range(n)]
+    ptr = np.concatenate([[0], np.cumsum([len(x) for x in rows])])
+    Hb = sp.csr_matrix((rng.standard_normal(ptr[-1]), np.concatenate(rows), ptr), shape=(n, k))
+    S = rand_csr(k, k, 0.004, 78); Q = (S + S.T).tocsr()
+    for H in (Ha, Hb):
+        H.sort_indices()
+        want = oracle.triple(arrays(H), arrays(Q), k, full=0)
+        h, q = ctx.csr_from_scipy(H), ctx.csr_from_scipy(Q)
+        try:
+            d1 = ctx.triple_host(h, q, exact=False)
+            e1 = ctx.triple_host(h, q, exact=True)
+            d2 = ctx.triple_host(h, q, exact=False)
+        finally:
+            h.close(); q.close()
+        assert np.array_equal(e1.view(np.int64), want.view(np.int64))
+        assert rel_err(d1, want) <= RTOL
+        assert rel_err(d2, want) <= RTOL
+
+
 def test_triple_row_range(ctx, oracle):
     H = rand_csr(200, 300, 0.05, 23); S = rand_csr(300, 300, 0.02, 24); Q = (S + S.T).tocsr()
     want = oracle.triple(arrays(H), arrays(Q), 300, full=0)
