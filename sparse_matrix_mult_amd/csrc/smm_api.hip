@@ -646,8 +646,8 @@ static int ensure_loc(smm_ctx *c, smm_csr *b, const Geom &g, const short **out)
 }
 
 // Sliced-ELL re-layout of H for triple-product stage 2 (see smm_triple_stage2); one copy is cached per
-// handle, for one chunk width and one order of the steps (spread = conflict-free order of the default mode,
-// stored order for SMM_EXACT).
+// handle, for one chunk width and one order of the steps (spread = any order inside a segment, the default
+// mode's; otherwise stored order with idle steps, SMM_EXACT's -- smm_ell_fill).
 static int ensure_ell(smm_ctx *c, smm_csr *h, int nchunks, int chunk, bool spread)
 {
     if (h->ell_val && h->ell_chunk == chunk && h->ell_nchunks == nchunks && h->ell_spread == spread) return SMM_OK;
@@ -683,8 +683,8 @@ static int ensure_ell(smm_ctx *c, smm_csr *h, int nchunks, int chunk, bool sprea
         hipMalloc((void **)&h->ell_val, (total + WAVE) * sizeof(double)) != hipSuccess)
         return fail(SMM_ERR_ALLOC, "hipMalloc of the ELL payload (%lld entries) failed", (long long)total);
     E.col = h->ell_col; E.val = h->ell_val;
-    if (spread) LAUNCH(c, "smm_ell_fill", smm_ell_fill<true>, grid, 256, 0, E);
-    else LAUNCH(c, "smm_ell_fill", smm_ell_fill<false>, grid, 256, 0, E);
+    if (spread) LAUNCH(c, "smm_ell_fill", smm_ell_fill<1>, grid, 256, 0, E);
+    else LAUNCH(c, "smm_ell_fill", smm_ell_fill<2>, grid, 256, 0, E);
     LAUNCH_CHECK();
     h->ell_chunk = chunk; h->ell_nchunks = nchunks; h->ell_spread = spread;
     return SMM_OK;

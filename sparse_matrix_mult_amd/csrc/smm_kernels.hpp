@@ -1369,9 +1369,10 @@ __global__ __launch_bounds__(256) void smm_dense_general(int m, int ncols, int64
 // T[i, col] * val, for k >= i (or all k), where T = H*Q is the dense n x K matrix stage 1
 // (smm_numeric<OUT_DENSE>) left in HBM.  With SMM_EXACT the sum runs in H's stored order starting
 // from 0.0, product rounded before the addition, exactly as the reference's scalar loop: stage 2 is
-// bit-exact given T.  By default the entries of a row inside one chunk are taken in the order that
-// keeps the LDS gather free of bank conflicts (smm_ell_fill<true>) and multiply-add is fused: the
-// same sum, within the 1e-10 of the default mode, at 1.4x the speed.
+// bit-exact given T (lanes only sit steps out to keep their LDS reads apart, smm_ell_fill<2>).  By
+// default the entries of a row inside one chunk are taken in whatever order keeps the LDS gather free
+// of bank conflicts (smm_ell_fill<1>) and multiply-add is fused: the same sum, within the 1e-10 of
+// the default mode.
 //
 // Layout.  A workgroup owns a block of R rows of T and a group of NW*64 rows k of H (one k per
 // lane, one 64-row slice per wave); its R running sums per lane stay in registers from the
@@ -1414,19 +1415,21 @@ __global__ __launch_bounds__(256) void smm_ell_count(const EllArgs A)
     if (lane == 0) A.cnt[item] = (int64_t)mx * WAVE;
 }
 
-// pass 2: payload (one wave per (chunk, slice)).
-// SPREAD = false (SMM_EXACT): step s of a lane is entry s of its segment -- the reference's order of additions.
-// SPREAD = true: the entries of a segment are dealt to the steps so that the 16 lanes of one ds_read_b128
-// conflict group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, the same + 32: MI355X_MICROARCH.md, LDS table) read
-// columns distinct mod 16 in every step.  Stage 2's tile is [column][R + 2] doubles with R = 16, so the 16-byte
-// slot of a lane's read j is (9 c + j) mod 16: distinct columns mod 16 = no bank conflict, where the stored
-// order costs 2.3 LDS passes per step (scripts/ubench/lds_conflict.hip: 1.65x the gather rate).  Greedy, one
-// step at a time: the lanes of a group choose one after the other the lowest residue class they still hold
-// an entry of and nobody in the group has taken in this step; a lane that finds none sits the step out while
-// it has steps to spare (the block is as long as the longest of the 64 segments, so most lanes do), and
-// takes a conflict otherwise.  Within a residue class the stored order is kept.  Blocks longer than 64 steps
-// stay in stored order.
-template <bool SPREAD>
+// pass 2: payload (one wave per (chunk, slice)).  Which entry of its segment a lane meets in which step decides
+// how often the wave's LDS reads collide in stage 2: the tile is [column][R + 2] doubles with R = 16, so the
+// 16-byte slot of a lane's read j is (9 c + j) mod 16, and the 16 lanes of one ds_read_b128 conflict group
+// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, the same + 32: MI355X_MICROARCH.md, LDS table) read without a bank
+// conflict iff their columns are distinct mod 16.  Entry s in step s costs 2.3 LDS passes per step on random
+// columns (scripts/ubench/lds_conflict.hip: 1.65x the gather rate without them).  The block is as long as the
+// longest of the 64 segments, so most lanes have steps to spare, and a scheduler uses them: step by step, the
+// lanes of a group choose in the order of their spare steps (fewest first); a lane whose candidate's residue
+// class is taken sits the step out (column -1) unless it has no step to spare, then it takes the conflict.
+//   ORDER 0  entry s in step s (blocks longer than 64 steps, whatever the mode)
+//   ORDER 1  default mode: the candidate is ANY entry the lane still holds (lowest free residue class; stored
+//            order inside a class) -- the order of additions changes, 1.06 passes per step
+//   ORDER 2  SMM_EXACT: the candidate is the NEXT entry in stored order, only idle steps are inserted -- the
+//            reference's order of additions, 1.3 passes per step
+template <int ORDER>
 __global__ __launch_bounds__(256) void smm_ell_fill(const EllArgs A)
 {
     __shared__ unsigned char s_ord[4][WAVE][64], s_ptr[4][WAVE][16], s_end[4][WAVE][16];
@@ -1443,7 +1446,7 @@ __global__ __launch_bounds__(256) void smm_ell_fill(const EllArgs A)
     const int64_t base = A.off[item];
     const int steps = (int)((A.off[item + 1] - base) / WAVE);
     const int lo = q * A.chunk;
-    if (!SPREAD || steps > 64) {
+    if (ORDER == 0 || steps > 64) {
         for (int st = 0; st < steps; ++st) {
             short c = -1; double v = 0.0;
             if (st < len) { c = (short)(A.h_idx[s + st] - lo); v = A.h_val[s + st]; }
@@ -1454,43 +1457,61 @@ __global__ __launch_bounds__(256) void smm_ell_fill(const EllArgs A)
     }
     const int w = threadIdx.x >> 6;
     unsigned char *ord = s_ord[w][lane], *ptr = s_ptr[w][lane], *end = s_end[w][lane];
-    // positions of the segment sorted by column mod 16 (stable): ord[ptr[r] .. end[r])
-    for (int r = 0; r < 16; ++r) ptr[r] = 0;
-    for (int p = 0; p < len; ++p) ++ptr[(A.h_idx[s + p] - lo) & 15];
-    {
+    unsigned avail = 0;
+    if (ORDER == 1) {
+        // positions of the segment sorted by column mod 16 (stable): ord[ptr[r] .. end[r])
+        for (int r = 0; r < 16; ++r) ptr[r] = 0;
+        for (int p = 0; p < len; ++p) ++ptr[(A.h_idx[s + p] - lo) & 15];
         int acc = 0;
         for (int r = 0; r < 16; ++r) { const int c = ptr[r]; ptr[r] = (unsigned char)acc; acc += c; }
+        for (int p = 0; p < len; ++p) ord[ptr[(A.h_idx[s + p] - lo) & 15]++] = (unsigned char)p;
+        for (int r = 15; r >= 0; --r) {
+            end[r] = ptr[r];
+            ptr[r] = r ? ptr[r - 1] : 0;
+        }
+        for (int r = 0; r < 16; ++r) avail |= (ptr[r] < end[r] ? 1u : 0u) << r;
+    } else {
+        for (int p = 0; p < len; ++p) ord[p] = (unsigned char)((A.h_idx[s + p] - lo) & 15);   // residue class of entry p
     }
-    for (int p = 0; p < len; ++p) ord[ptr[(A.h_idx[s + p] - lo) & 15]++] = (unsigned char)p;
-    unsigned avail = 0;
-    for (int r = 15; r >= 0; --r) {
-        end[r] = ptr[r];
-        ptr[r] = r ? ptr[r - 1] : 0;
-    }
-    for (int r = 0; r < 16; ++r) avail |= (ptr[r] < end[r] ? 1u : 0u) << r;
-    // conflict group and position in it
+    // conflict group and position in it; lane at position i of this lane's group
     const int l32 = lane & 31;
     const int odd = (l32 >= 4 && l32 < 12) || (l32 >= 16 && l32 < 20) || l32 >= 28;
     const int gp = l32 < 4 ? l32 : l32 < 12 ? l32 - 4 : l32 < 20 ? l32 - 8 : l32 < 28 ? l32 - 12 : l32 - 16;
-    int rem = len;
+    auto at = [&](int i) { return (lane & 32) + (odd ? (i < 8 ? i + 4 : i < 12 ? i + 8 : i + 16) : (i < 4 ? i : i < 8 ? i + 8 : i + 12)); };
+    int rem = len, next = 0;
     for (int st = 0; st < steps; ++st) {
-        const int left = steps - st;
+        const int spare = rem > 0 ? steps - st - rem : 255;          // 0: this lane must take an entry in every step left
+        const int key = (spare << 4) | gp;
+        int rank = 0;
+        for (int i = 0; i < 16; ++i) rank += __shfl(key, at(i)) < key ? 1 : 0;
+        // the lane at position j of the group learns which lane chooses j-th
+        const int chooser = __builtin_amdgcn_ds_permute(at(rank) << 2, lane);
         unsigned used = 0; int pick = -1;
-        for (int i = 0; i < 16; ++i) {
+        for (int j = 0; j < 16; ++j) {
+            const int who = __shfl(chooser, at(j));
             unsigned bit = 0;
-            if (gp == i && rem > 0) {
-                const unsigned m = avail & ~used;
-                if (m) pick = __ffs(m) - 1;
-                else if (rem >= left) pick = __ffs(avail) - 1;       // no step to spare: take the conflict
+            if (lane == who && rem > 0) {
+                if (ORDER == 1) {
+                    const unsigned m = avail & ~used;
+                    if (m) pick = __ffs(m) - 1;
+                    else if (spare == 0) pick = __ffs(avail) - 1;    // no step to spare: take the conflict
+                } else {
+                    const int r = ord[next];
+                    if (!((used >> r) & 1u) || spare == 0) pick = r;
+                }
                 if (pick >= 0) bit = 1u << pick;
             }
-            const int src = (lane & 32) + (odd ? (i < 8 ? i + 4 : i < 12 ? i + 8 : i + 16) : (i < 4 ? i : i < 8 ? i + 8 : i + 12));
-            used |= (unsigned)__shfl((int)bit, src);
+            used |= (unsigned)__shfl((int)bit, who);
         }
         short c = -1; double v = 0.0;
         if (pick >= 0) {
-            const int p = ord[ptr[pick]];
-            if (++ptr[pick] == end[pick]) avail &= ~(1u << pick);
+            int p;
+            if (ORDER == 1) {
+                p = ord[ptr[pick]];
+                if (++ptr[pick] == end[pick]) avail &= ~(1u << pick);
+            } else {
+                p = next++;
+            }
             --rem;
             c = (short)(A.h_idx[s + p] - lo); v = A.h_val[s + p];
         }
