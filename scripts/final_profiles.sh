@@ -14,5 +14,8 @@ python3 bench.py --config c2 --steps 5 --exact > gpurun_out/${TAG}_bench_c2_exac
 python3 bench.py --config c3 --steps 3 --warmup 1 > gpurun_out/${TAG}_bench_c3.json 2>> gpurun_out/${TAG}_bench.err
 python3 bench.py --config c3 --steps 3 --warmup 1 --exact > gpurun_out/${TAG}_bench_c3_exact.json 2>> gpurun_out/${TAG}_bench.err
 python3 bench.py --config c4 --steps 3 --warmup 1 --no-cpu > gpurun_out/${TAG}_bench_c4.json 2>> gpurun_out/${TAG}_bench.err
+bash scripts/pmc_run.sh ${TAG}_c3 --config c3 > /dev/null 2>&1
+# only the summaries travel back (gpurun merges at most 64 MiB)
+rm -rf gpurun_out/pmc_$TAG gpurun_out/pmc_${TAG}_c3 gpurun_out/prof_$TAG
 cut -c1-160 gpurun_out/${TAG}_kernel_stats.csv | head -8
 for f in gpurun_out/${TAG}_bench_c*.json; do echo $f; cut -c1-330 $f; done
