@@ -1494,9 +1494,12 @@ extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags,
         if (mirror) CHK(mirror_upper(c, n, d_c, n));
         return SMM_OK;
     }
-    constexpr int NW = 16;
+#ifndef SMM_S2_NW
+#define SMM_S2_NW 16
+#endif
+    constexpr int NW = SMM_S2_NW;          // waves per workgroup = 64-row slices of H per k-group
     constexpr int R = 16;
-    const int chunk_cap = 1024;            // [chunk][R+2] f64 = 144 KB of LDS
+    constexpr int chunk_cap = NW * 64;     // one tile column per thread; [chunk][R+2] f64 = 144 KB of LDS at 16 waves
     const int nchunks = (int)((K + chunk_cap - 1) / chunk_cap);
     const int chunk = (int)((K + nchunks - 1) / nchunks);
     const bool exact = (flags & SMM_EXACT) != 0;
@@ -1510,7 +1513,7 @@ extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags,
     A.T = T; A.C = d_c; A.ldc = n;
     const size_t lds = (size_t)(R + 2) * chunk * sizeof(double);
     const int64_t nkg = (n + NW * WAVE - 1) / (NW * WAVE);
-    auto kern = exact ? smm_triple_stage2<R, NW, 1024, false> : smm_triple_stage2<R, NW, 1024, true>;
+    auto kern = exact ? smm_triple_stage2<R, NW, chunk_cap, false> : smm_triple_stage2<R, NW, chunk_cap, true>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { pool_free(c, T); return fail(SMM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e)); }

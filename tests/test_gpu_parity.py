@@ -272,6 +272,26 @@ def test_triple_step_order_edge_cases(ctx, oracle):
         assert rel_err(d2, want) <= RTOL
 
 
+@pytest.mark.parametrize("exact", MODES)
+def test_triple_many_k_groups(ctx, oracle, exact):
+    """7 k-groups of 1024 rows = two super-groups of the stage-2 block order (5 + 2), a row-block count that is
+    not a multiple of 8 and a last k-group that is mostly past n; the whole result against the oracle."""
+    n, k = 6200, 320
+    H = rand_csr(n, k, 0.02, 91); S = rand_csr(k, k, 0.03, 92); Q = (S + S.T).tocsr()
+    h, q = ctx.csr_from_scipy(H), ctx.csr_from_scipy(Q)
+    try:
+        for full in (0, 1):
+            want = oracle.triple(arrays(H), arrays(Q), k, full=full)
+            got = ctx.triple_host(h, q, full=bool(full), exact=exact)
+            if exact:
+                assert np.array_equal(got.view(np.int64), want.view(np.int64)), f"full={full}: max rel {rel_err(got, want):.3e}"
+            else:
+                assert rel_err(got, want) <= RTOL
+            del want, got
+    finally:
+        h.close(); q.close()
+
+
 def test_triple_row_range(ctx, oracle):
     H = rand_csr(200, 300, 0.05, 23); S = rand_csr(300, 300, 0.02, 24); Q = (S + S.T).tocsr()
     want = oracle.triple(arrays(H), arrays(Q), 300, full=0)
