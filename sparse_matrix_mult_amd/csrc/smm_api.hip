@@ -1522,7 +1522,22 @@ extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags,
     A.gk = (int)std::min<int64_t>(std::max(c->s2_group, 1), nkg);
     const int64_t grid2 = ((nkg + A.gk - 1) / A.gk) * A.gk * (((int64_t)A.nib + 7) / 8) * 8;
     if (grid2 > 0x7fffffff) { pool_free(c, T); return fail(SMM_ERR_INVALID, "triple product too large for one launch"); }
+#ifdef SMM_S2_STAMPS
+    unsigned long long *d_st = nullptr;
+    if (pool_get(c, 8, &d_st) == SMM_OK) { (void)hipMemsetAsync(d_st, 0, 64, c->stream); A.stamps = d_st; }
+#endif
     LAUNCH(c, "smm_triple_stage2", kern, grid2, NW * 64, lds, A);
+#ifdef SMM_S2_STAMPS
+    if (d_st) {
+        unsigned long long hst[8];
+        (void)hipMemcpyAsync(hst, d_st, 64, hipMemcpyDeviceToHost, c->stream);
+        (void)hipStreamSynchronize(c->stream);
+        double tot = 0; for (int i = 0; i < 6; ++i) tot += (double)hst[i];
+        fprintf(stderr, "[SMM_S2_STAMPS] wave-cycles %.4g: preload issue %.1f%%  barrier 1 %.1f%%  tile write %.1f%%  barrier 2 %.1f%%  tile load issue %.1f%%  steps %.1f%%\n",
+                tot, 100 * hst[0] / tot, 100 * hst[1] / tot, 100 * hst[2] / tot, 100 * hst[3] / tot, 100 * hst[4] / tot, 100 * hst[5] / tot);
+        pool_free(c, d_st);
+    }
+#endif
     if (full) LAUNCH(c, "smm_triple_mirror", smm_triple_mirror, (n * n + 255) / 256, 256, 0, (int)n, d_c, n);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // T returns to the pool below

@@ -1529,12 +1529,16 @@ struct TripleArgs {
     const short *col; const double *val;
     const double *T;                  // (row_end-row_begin) x K
     double *C; int64_t ldc;           // row row_begin at C
+    unsigned long long *stamps;       // diagnostic builds (-DSMM_S2_STAMPS) only: cycles per phase, summed over waves
 };
 
 // diagnostic builds (make variant EXTRA=-DSMM_S2_DIAG=n): 1 = no loads of T, 4 = no barriers, 16 = every block
 // loads the tiles of row block 0 (L2 hits).  Wrong results, timing only.
 #ifndef SMM_S2_DIAG
 #define SMM_S2_DIAG 0
+#endif
+#ifndef SMM_S2_STAGGER
+#define SMM_S2_STAGGER 4
 #endif
 #ifndef SMM_S2_DEPTH
 #define SMM_S2_DEPTH 8
@@ -1544,9 +1548,19 @@ struct TripleArgs {
 #else
 #define S2_SYNC() __syncthreads()
 #endif
+#ifdef SMM_S2_STAMPS
+#define S2_MARK() (t_mark = __builtin_readcyclecounter())
+#define S2_LAP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); t_ph[i] += now_ - t_mark; t_mark = now_; }
+#else
+#define S2_MARK()
+#define S2_LAP(i)
+#endif
 template <int R, int NW, int CW, bool FMA>
 __global__ __launch_bounds__(NW * 64) void smm_triple_stage2(const TripleArgs A)
 {
+#ifdef SMM_S2_STAMPS
+    unsigned long long t_ph[6] = {0, 0, 0, 0, 0, 0}, t_mark;
+#endif
     constexpr int RP = NW * 64 / CW;                   // tile rows filled per pass (chunk <= CW columns)
     constexpr int NV = R / RP;                         // tile elements per thread
     static_assert(RP >= 1 && RP * CW == NW * 64 && R % (2 * RP) == 0 && NV == 16, "tile fill: CW threads per row");
@@ -1632,17 +1646,24 @@ __global__ __launch_bounds__(NW * 64) void smm_triple_stage2(const TripleArgs A)
         // chunk: 14 of 55 ms at BASELINE configs[3].)
         const int last = steps > 0 ? steps - 1 : 0;
         int cc[D]; double hh[D];
+        S2_MARK();
 #pragma unroll
         for (int u = 0; u < D; ++u) {
             const int su = u < last ? u : last;
             cc[u] = cp[(int64_t)su * WAVE]; hh[u] = vp[(int64_t)su * WAVE];
         }
+        S2_LAP(0);
         S2_SYNC();                               // nobody reads the previous tile any more
+        S2_LAP(1);
         if (fx < w) {
             double *dst = tl + fx * LD + fr;
 #pragma unroll
             for (int t = 0; t < NV; ++t) dst[RP * t] = v[t];
         }
+#ifdef SMM_S2_STAMPS
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the tile writes have landed
+#endif
+        S2_LAP(2);
         const int qn = q + 1 < A.nchunks ? q + 1 : q;
         {
             const int mi = __builtin_amdgcn_readfirstlane(qn * A.nslices + slc);    // wave-uniform: scalar loads
@@ -1651,11 +1672,13 @@ __global__ __launch_bounds__(NW * 64) void smm_triple_stage2(const TripleArgs A)
         const int lon = qn * A.chunk;
         const int wn = (A.K - lon) < A.chunk ? (A.K - lon) : A.chunk;
         S2_SYNC();
-#pragma unroll
-        for (int t = 0; t < NV; ++t) TILE_LD(t, lon, wn);
-        // The first D steps stand in front of the loop: their entries were requested before the burst, and only
-        // in straight-line code does the compiler count the loads that may still be in flight exactly
-        // (s_waitcnt vmcnt(NV + 2u)); inside the loop it has to assume the back edge's 2(D-1).
+        S2_LAP(3);
+        // The 16 waves' tile loads are 128 KB through a 64 B/clk vector-memory pipe: issued by all waves at once
+        // behind the barrier they block every wave at the issue for ~2000 cycles (13 % of the kernel in a stamped
+        // build) while the LDS pipe idles.  So the waves take turns: wave w issues its NV loads in front of step
+        // group w mod S2_STAGGER, the others gather meanwhile.  (One unconditional site for the loads between two
+        // copies of the step loop: with the loads under a condition inside the loop the compiler spilled 99 VGPRs.)
+        S2_LAP(4);
 #define STEP_GROUP(st_)                                                                         \
         _Pragma("unroll") for (int u = 0; u < D; ++u) {                                         \
             if ((st_) + u < steps && cc[u] >= 0) {                                              \
@@ -1669,10 +1692,23 @@ __global__ __launch_bounds__(NW * 64) void smm_triple_stage2(const TripleArgs A)
             const int sn = (st_) + u + D < last ? (st_) + u + D : last;                         \
             cc[u] = cp[(int64_t)sn * WAVE]; hh[u] = vp[(int64_t)sn * WAVE];                     \
         }
-        STEP_GROUP(0)
-        for (int st = D; st < steps; st += D) { STEP_GROUP(st) }
+        {
+            const int ng = steps > D ? (steps + D - 1) / D : 1;        // at least one group: the tile loads must go out
+            int tg = wave % SMM_S2_STAGGER;
+            tg = tg < ng ? tg : ng - 1;
+            int g = 0;
+            for (; g < tg; ++g) { STEP_GROUP(g * D) }
+#pragma unroll
+            for (int t = 0; t < NV; ++t) TILE_LD(t, lon, wn);
+            for (; g < ng; ++g) { STEP_GROUP(g * D) }
+        }
 #undef STEP_GROUP
+        S2_LAP(5);
     }
+#ifdef SMM_S2_STAMPS
+    if (lane == 0 && work && A.stamps)
+        for (int i = 0; i < 6; ++i) atomicAdd(&A.stamps[i], t_ph[i]);
+#endif
 #undef TILE_LD
     if (kin) {
 #pragma unroll
