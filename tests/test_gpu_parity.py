@@ -292,6 +292,25 @@ def test_triple_many_k_groups(ctx, oracle, exact):
         h.close(); q.close()
 
 
+@pytest.mark.parametrize("group", [1, 2, 3, 7])
+def test_triple_block_order_variants(oracle, group, monkeypatch):
+    """SMM_S2_GROUP (k-groups per super-group of the stage-2 block order) only permutes workgroups: every value
+    gives the same bits, also when it does not divide the number of k-groups (3 here) or exceeds it."""
+    from sparse_matrix_mult_amd.engine import Context
+    monkeypatch.setenv("SMM_S2_GROUP", str(group))
+    n, k = 2200, 300
+    H = rand_csr(n, k, 0.03, 95); S = rand_csr(k, k, 0.03, 96); Q = (S + S.T).tocsr()
+    want = oracle.triple(arrays(H), arrays(Q), k, full=0)
+    c2 = Context(0)
+    try:
+        h, q = c2.csr_from_scipy(H), c2.csr_from_scipy(Q)
+        got = c2.triple_host(h, q, exact=True)
+        h.close(); q.close()
+    finally:
+        c2.close()
+    assert np.array_equal(got.view(np.int64), want.view(np.int64))
+
+
 def test_triple_row_range(ctx, oracle):
     H = rand_csr(200, 300, 0.05, 23); S = rand_csr(300, 300, 0.02, 24); Q = (S + S.T).tocsr()
     want = oracle.triple(arrays(H), arrays(Q), 300, full=0)
