@@ -1538,10 +1538,10 @@ struct TripleArgs {
 #define SMM_S2_DIAG 0
 #endif
 #ifndef SMM_S2_STAGGER
-#define SMM_S2_STAGGER 4
+#define SMM_S2_STAGGER 8
 #endif
 #ifndef SMM_S2_DEPTH
-#define SMM_S2_DEPTH 8
+#define SMM_S2_DEPTH 3
 #endif
 #if SMM_S2_DIAG & 4
 #define S2_SYNC() __builtin_amdgcn_sched_barrier(0)
@@ -1639,11 +1639,10 @@ __global__ __launch_bounds__(NW * 64) void smm_triple_stage2(const TripleArgs A)
         const double *vp = A.val + base_n + lane;
         // The entries of the next D steps travel in registers (indices are clamped into the slice's block; a
         // clamped step has st >= steps and adds nothing).  vmcnt retires in order, so a wait for an H entry
-        // also waits for every tile load issued before it: the NV loads of the NEXT chunk's tile go out in
-        // one burst behind the first D steps' entries, and the entries requested after the burst are not
-        // needed before D steps of gathers have run -- the HBM round trip of the tile hides behind them.
-        // (Two tile loads per step pair, as this loop did before, exposed that round trip NV/2 times per
-        // chunk: 14 of 55 ms at BASELINE configs[3].)
+        // also waits for every tile load issued before it; the NV loads of the NEXT chunk's tile therefore go
+        // out in one burst per wave (see below for when).  D = 3 with the waves' bursts spread over 8 step
+        // groups measured best (50.7 ms at BASELINE configs[3]; D = 8 / 4 groups 53.6, D = 2 54-55: sweep in
+        // profiles/r2_s2_sweeps.txt) -- a short ring leaves the registers to the LDS reads in flight.
         const int last = steps > 0 ? steps - 1 : 0;
         int cc[D]; double hh[D];
         S2_MARK();
