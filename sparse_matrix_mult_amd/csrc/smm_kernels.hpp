@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void smm_pack_count(int rows, int nct, const i
     const int t = (int)(gid / rows), j = (int)(gid % rows);
     const int *sp = seg + (size_t)j * (nct + 1) + t;
     const int len = sp[1] - sp[0];
-    units[gid] = len + ((len + 3) >> 2);
+    units[gid] = (len + ((len + 3) >> 2) + 1) & ~1;        // 16-byte pieces: the wide-chunk walk loads value pairs
 }
 __global__ __launch_bounds__(256) void smm_pack_desc(int rows, int nct, const int *__restrict__ seg, const int64_t *__restrict__ off,
                                                      int2 *__restrict__ desc)
@@ -883,6 +883,9 @@ __device__ __forceinline__ void smm_accumulate(const NumericArgs &A, double *__r
 // (Measured dead end: the EXEC-masked, scalar-base chunk loads of smm_symbolic applied here made the
 // kernel slower, 29.5 -> 30.6 ms: it is bound by the gather, not by instruction issue, and the scalar
 // address arithmetic between the loads spreads their issue out.)
+#ifndef SMM_WIDE_CHUNKS
+#define SMM_WIDE_CHUNKS 1
+#endif
 #ifndef SMM_CH_UNROLL
 #define SMM_CH_UNROLL 8
 #endif
@@ -910,6 +913,43 @@ __device__ __forceinline__ void smm_accumulate_shared(const NumericArgs &A, doub
         const int2 d = desc[r];                     // {first 8-byte unit of the piece, entries}
         const int s_l = d.x;
         const int n_l = ev ? d.y : 0;
+#if SMM_WIDE_CHUNKS
+        // chunks of 128 entries: one 16-byte load (two values) and one 4-byte load (two columns) per lane
+        typedef double dpair __attribute__((ext_vector_type(2), aligned(8)));
+        const int nch = (n_l + 2 * WAVE - 1) >> 7;
+        const int incl = wave_scan_incl(nch);
+        const int total = rl(incl, WAVE - 1);
+        for (int t0 = 0; t0 < total; t0 += CH_UNROLL) {
+            int c[CH_UNROLL], own[CH_UNROLL];
+            dpair v[CH_UNROLL];
+#pragma unroll
+            for (int u = 0; u < CH_UNROLL; ++u) {       // every load first ...
+                const int t = t0 + u;
+                int i = (int)__popcll(__ballot(incl <= t));
+                i = i < WAVE ? i : WAVE - 1;
+                own[u] = i;
+                const int first = rl(incl, i) - rl(nch, i);
+                const int s = rl(s_l, i), n = rl(n_l, i);
+                const int k = ((t - first) << 7) + 2 * lane;
+                const bool p = t < total && k < n;
+                // a last, single entry reads one element past the values (the piece's own column block) and one
+                // past the columns (their padding): both inside the piece, the second half is dropped below
+                const dpair *vp = reinterpret_cast<const dpair *>(p ? pay + s + k : A.dummy_val);
+                const int *ip = reinterpret_cast<const int *>(p ? (const short *)(pay + s + n) + k : dummy_c);
+                int cc = *ip;
+                if (!(t < total && k + 1 < n)) cc |= (int)0xffff0000;       // no second entry: column -1
+                c[u] = cc;
+                v[u] = *vp;
+            }
+#pragma unroll
+            for (int u = 0; u < CH_UNROLL; ++u) {       // ... then the adds
+                const int c0 = (int)(short)(c[u] & 0xffff), c1 = c[u] >> 16;
+                const double a = rl(av, own[u]);
+                if (c0 >= thresh) lds_add(&acc[c0], a * v[u].x);
+                if (c1 >= thresh) lds_add(&acc[c1], a * v[u].y);
+            }
+        }
+#else
         const int nch = (n_l + WAVE - 1) >> 6;
         const int incl = wave_scan_incl(nch);
         const int total = rl(incl, WAVE - 1);
@@ -935,6 +975,7 @@ __device__ __forceinline__ void smm_accumulate_shared(const NumericArgs &A, doub
             for (int u = 0; u < CH_UNROLL; ++u)         // ... then the adds
                 if (c[u] >= thresh) lds_add(&acc[c[u]], rl(av, own[u]) * v[u]);
         }
+#endif
     }
 }
 
