@@ -64,6 +64,7 @@ struct smm_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool timing = false;
+    int sym_wide = 1;        // symbolic phase on 16-bit columns: chunks of 128 entries (env SMM_SYM_WIDE=0: 64)
     int s2_group = 5;        // triple stage 2: k-groups whose blocks follow each other on one XCD and share a tile of T
                              // through its L2 (env SMM_S2_GROUP; at BASELINE configs[3] 1: 58.2, 2: 56.3, 4: 60.1, 5: 54.8,
                              // 7: 54.9, 8: 58.9, 10: 54.8 ms -- powers of two lose, profiles/r2_s2_sweeps.txt)
@@ -184,6 +185,7 @@ extern "C" int smm_ctx_create(int device, void *hip_stream, smm_ctx **out)
     c->device = device;
     if (const char *e = getenv("SMM_NARROW_IDX")) c->narrow_idx = atoi(e) != 0;     // A/B switch (scripts/ab_env.sh)
     if (const char *e = getenv("SMM_S2_GROUP")) c->s2_group = std::max(1, atoi(e));
+    if (const char *e = getenv("SMM_SYM_WIDE")) c->sym_wide = atoi(e) != 0;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hip_stream == SMM_STREAM_DEFAULT) { c->stream = nullptr; c->own_stream = false; }   // the device's null stream
     else if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
@@ -617,7 +619,8 @@ static int ensure_idx16(smm_ctx *c, smm_csr *b)
 {
     if (b->idx16) return SMM_OK;
     if (b->cols >= 65535) return fail(SMM_ERR_INVALID, "16-bit column copy needs < 65535 columns");
-    if (hipMalloc((void **)&b->idx16, std::max<int64_t>(b->nnz, 1) * sizeof(unsigned short)) != hipSuccess)
+    // + 2 entries of slack: the wide symbolic walk reads columns in pairs
+    if (hipMalloc((void **)&b->idx16, (std::max<int64_t>(b->nnz, 1) + 2) * sizeof(unsigned short)) != hipSuccess)
         return fail(SMM_ERR_ALLOC, "hipMalloc of the 16-bit column copy failed");
     if (b->nnz > 0) {
         LAUNCH(c, "smm_idx16", smm_idx16, std::min<int64_t>((b->nnz + 255) / 256, 65536), 256, 0, (int)b->nnz, b->idx, b->idx16);
@@ -1029,6 +1032,21 @@ static int launch_symbolic_w(smm_ctx *c, smm_plan *p, int words, unsigned *gbm, 
     // LDS per wave: bitmap words + the guard word, or the hash slots
     const size_t lds = MARK == MARK_GLOBAL_BITMAP ? 0 : (size_t)(words + (MARK == MARK_LDS_HASH ? 0 : 1)) * wpb * sizeof(unsigned);
     auto kern = smm_symbolic<SYM, SAFE, MARK, UNROLL, I16>;
+#ifndef SMM_SYMW_UNROLL
+#define SMM_SYMW_UNROLL 4
+#endif
+#ifndef SMM_SYMW_DEEP
+#define SMM_SYMW_DEEP 16
+#endif
+    if constexpr (!SAFE && MARK != MARK_LDS_HASH) {
+        // chunks of 128 entries, two columns per lane (16-bit columns: the idle column must fit 16 bits)
+        // The pair of an odd chunk's last entry reaches one column past the row.  The 16-bit copy has slack for
+        // that; the caller's own 32-bit array is read one int past its end only if that int lies in the page
+        // of the last entry (a 4-byte read cannot leave a mapped page unless the array ends on a page boundary).
+        const bool tail_ok = I16 || (((uintptr_t)(p->b->idx + p->b->nnz)) & 4095u) != 0;
+        if (c->sym_wide && tail_ok && (!I16 || words * 32 + 31 <= 65535))
+            kern = smm_symbolic<SYM, false, MARK, (UNROLL == 16 ? SMM_SYMW_UNROLL : SMM_SYMW_DEEP), I16, true>;
+    }
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     LAUNCH(c, MARK == MARK_LDS_HASH ? "smm_symbolic_hash" : "smm_symbolic", kern, grid, wpb * 64, lds, (int)p->m, rowlist,

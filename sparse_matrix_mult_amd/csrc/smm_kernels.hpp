@@ -119,6 +119,32 @@ __device__ __forceinline__ void load_masked(int &v, const unsigned short *idx, u
                  : "+v"(v)
                  : "v"(lane2), "s"(idx), "s"(mask));
 }
+// two neighbouring 16-bit columns per lane (one dword at a 2-byte aligned address): per-lane offset 4*lane
+__device__ __forceinline__ void load_masked_pair(int &v, const unsigned short *idx, unsigned long long mask, int lane4) {
+    asm volatile("s_mov_b64 exec, %3\n\t"
+                 "global_load_dword %0, %1, %2\n\t"
+                 "s_mov_b64 exec, -1"
+                 : "+v"(v)
+                 : "v"(lane4), "s"(idx), "s"(mask));
+}
+// two neighbouring 32-bit columns per lane (one dwordx2): per-lane offset 8*lane
+__device__ __forceinline__ void load_masked_pair(long long &v, const int *idx, unsigned long long mask, int lane8) {
+    asm volatile("s_mov_b64 exec, %3\n\t"
+                 "global_load_dwordx2 %0, %1, %2\n\t"
+                 "s_mov_b64 exec, -1"
+                 : "+v"(v)
+                 : "v"(lane8), "s"(idx), "s"(mask));
+}
+__device__ __forceinline__ void wait_vm(long long &v, int n) {
+#define SMM_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(v)); break;
+    switch (n) {
+        SMM_W(0) SMM_W(1) SMM_W(2) SMM_W(3) SMM_W(4) SMM_W(5) SMM_W(6) SMM_W(7)
+        SMM_W(8) SMM_W(9) SMM_W(10) SMM_W(11) SMM_W(12) SMM_W(13) SMM_W(14) SMM_W(15)
+        SMM_W(16) SMM_W(17) SMM_W(18) SMM_W(19) SMM_W(20) SMM_W(21) SMM_W(22) SMM_W(23)
+        SMM_W(24) SMM_W(25) SMM_W(26) SMM_W(27) SMM_W(28) SMM_W(29) SMM_W(30) SMM_W(31)
+    }
+#undef SMM_W
+}
 // n is a constant after unrolling; the switch folds to one s_waitcnt
 __device__ __forceinline__ void wait_vm(int &v, int n) {
 #define SMM_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(v)); break;
@@ -130,8 +156,8 @@ __device__ __forceinline__ void wait_vm(int &v, int n) {
     }
 #undef SMM_W
 }
-template <int N>
-__device__ __forceinline__ void wait_vm_all(int (&v)[N]) {
+template <typename T, int N>
+__device__ __forceinline__ void wait_vm_all(T (&v)[N]) {
 #pragma unroll
     for (int u = 0; u < N; ++u) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[u]));
 }
@@ -404,7 +430,10 @@ __global__ __launch_bounds__(1024) void smm_scan_tiles(int n, const T *__restric
 // 50 000 columns, 24 waves); 32 when the bitmap leaves few waves per CU and a round is pure latency.
 enum { MARK_LDS_BITMAP = 0, MARK_GLOBAL_BITMAP = 1, MARK_LDS_HASH = 2 };
 // I16: B's columns are read from the 16-bit copy (smm_idx16) and the lists are written as uint16.
-template <bool SYM, bool SAFE, int MARK, int SYM_UNROLL, bool I16 = false>
+// WIDE (bitmap marker, no repeated columns): chunks of 128 entries, a lane loads two neighbouring columns with
+// one dword / dwordx2 load -- the per-chunk work (descriptor, EXEC set-up, load, wait) is spent once per 128
+// products instead of once per 64.  With 16-bit columns the idle column must fit 16 bits (columns <= 65 504).
+template <bool SYM, bool SAFE, int MARK, int SYM_UNROLL, bool I16 = false, bool WIDE = false>
 __global__ __launch_bounds__(256) void smm_symbolic(int m, const int *__restrict__ rowlist,
                                                     const int *__restrict__ nrows_p, int64_t row_offset, int bm_words,
                                                     const int *__restrict__ a_ptr,
@@ -424,6 +453,9 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, const int *__restrict
     IT *__restrict__ tmp_idx = (IT *)tmp_idx_v;
     constexpr bool HASH = MARK == MARK_LDS_HASH;
     static_assert(!(HASH && SAFE), "rows of B with repeated columns take the bitmap kernels");
+    static_assert(!WIDE || (!SAFE && !HASH), "wide chunks: bitmap marker, no repeated columns");
+    constexpr int CSH = WIDE ? 7 : 6;                  // log2 of the entries per chunk
+    constexpr int CHN = 1 << CSH;
     const int lane = lane_id();
     const int lane4 = lane * 4;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -478,7 +510,7 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, const int *__restrict
                 // (vmcnt retires in order).
                 asm volatile("" : "+v"(bs), "+v"(be));
                 // entry `lane` of the batch owns the chunks [excl, incl) of the batch's chunk list
-                const int nch = lane < nb ? (be - bs + WAVE - 1) >> 6 : 0;
+                const int nch = lane < nb ? (be - bs + CHN - 1) >> CSH : 0;
                 const int incl = wave_scan_incl(nch);
                 const int excl = incl - nch;
                 const int T = rl(incl, WAVE - 1);
@@ -490,25 +522,34 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, const int *__restrict
 #pragma unroll
                     for (int sft = WAVE / 2; sft > 0; sft >>= 1)
                         if (__shfl(incl, ej + sft - 1) <= t) ej += sft;
-                    const int start = __shfl(bs, ej) + (t - __shfl(excl, ej)) * WAVE;
+                    const int start = __shfl(bs, ej) + (t - __shfl(excl, ej)) * CHN;
                     const int cnt = __shfl(be, ej) - start;             // >= 1 for t < T
-                    const unsigned long long lm = t >= T ? 0ull : cnt >= WAVE ? ~0ull : (1ull << cnt) - 1ull;
+                    const int nl = WIDE ? (cnt + 1) >> 1 : cnt;         // lanes that load
+                    const unsigned long long lm = t >= T ? 0ull : nl >= WAVE ? ~0ull : (1ull << nl) - 1ull;
+                    const int d_cnt = cnt;                              // WIDE: lane l holds entries 2l, 2l+1 < cnt
                     const unsigned d_off = t < T ? (unsigned)start : 0u, d_lo = (unsigned)lm, d_hi = (unsigned)(lm >> 32);
                     const int G = T - tg < WAVE ? T - tg : WAVE;
                     int nrec = 0;                                       // lane t: length of the list before chunk t
                     for (int rb = 0; rb < G; rb += SYM_UNROLL) {
+                        constexpr bool W32 = WIDE && !I16;              // pairs of 32-bit columns travel in 64-bit registers
                         int c[SYM_UNROLL];
+                        long long cq[W32 ? SYM_UNROLL : 1];
 #pragma unroll
-                        for (int u = 0; u < SYM_UNROLL; ++u) c[u] = idle;       // idle lanes / dead slots
+                        for (int u = 0; u < SYM_UNROLL; ++u) {          // idle lanes / dead slots
+                            if constexpr (W32) cq[u] = (long long)(((unsigned long long)(unsigned)idle << 32) | (unsigned)idle);
+                            else c[u] = WIDE ? (idle | (idle << 16)) : idle;
+                        }
 #pragma unroll
                         for (int u = 0; u < SYM_UNROLL; ++u) {                  // all loads first (MLP)
                             const int tt = rb + u;
                             const unsigned long long mk = ((unsigned long long)rl(d_hi, tt) << 32) | rl(d_lo, tt);
-                            load_masked(c[u], b_idx + rl(d_off, tt), mk, lane4);
+                            if constexpr (W32) load_masked_pair(cq[u], (const int *)b_idx + rl(d_off, tt), mk, lane4 * 2);
+                            else if constexpr (WIDE) load_masked_pair(c[u], (const unsigned short *)b_idx + rl(d_off, tt), mk, lane4);
+                            else load_masked(c[u], b_idx + rl(d_off, tt), mk, lane4);
                         }
                         // chunk u of a full round has SYM_UNROLL-1-u younger loads behind it; in a partial
                         // round the dead slots may not count at all (EXEC = 0), so it simply drains
-                        if (rb + SYM_UNROLL > G) wait_vm_all(c);
+                        if (rb + SYM_UNROLL > G) { if constexpr (W32) wait_vm_all(cq); else wait_vm_all(c); }
                         if constexpr (HASH) {
                             // chunk after chunk: look the columns up in the set, insert the unseen ones
                             // (linear probing; the columns of one chunk are distinct, so two lanes
@@ -534,6 +575,43 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, const int *__restrict
                                                                   __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)n))] = (IT)c[u];
                                 n += __popcll(mask);
                             }
+                        } else if constexpr (WIDE) {
+                        // two columns per lane: entry 2l (low half) and 2l+1 (high half; the last lane of an
+                        // odd chunk read one column too many: made idle).  Columns of one chunk are distinct, so
+                        // the order of the two test-and-sets inside a chunk does not matter; the list order
+                        // does: entry 2l, then 2l+1, lane after lane.
+                        unsigned oldl[SYM_UNROLL], oldh[SYM_UNROLL], bitl[SYM_UNROLL], bith[SYM_UNROLL];
+                        int ch[SYM_UNROLL];
+#pragma unroll
+                        for (int u = 0; u < SYM_UNROLL; ++u) {
+                            int lo, hi;
+                            if constexpr (W32) {
+                                wait_vm(cq[u], SYM_UNROLL - 1 - u);
+                                lo = (int)(unsigned)cq[u]; hi = (int)(unsigned)((unsigned long long)cq[u] >> 32);
+                            } else {
+                                wait_vm(c[u], SYM_UNROLL - 1 - u);
+                                lo = c[u] & 0xffff; hi = (int)((unsigned)c[u] >> 16);
+                            }
+                            const int cn = rl(d_cnt, (rb + u) & (WAVE - 1));
+                            if (2 * lane + 1 >= cn) hi = idle;
+                            if (SYM) { lo = lo >= thresh ? lo : idle; hi = hi >= thresh ? hi : idle; }
+                            c[u] = lo; ch[u] = hi;
+                            bitl[u] = 1u << (lo & 31); bith[u] = 1u << (hi & 31);
+                            oldl[u] = atomicOr(bm + (lo >> 5), bitl[u]);
+                            oldh[u] = atomicOr(bm + (hi >> 5), bith[u]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < SYM_UNROLL; ++u) {
+                            if (lane == rb + u) nrec = n;
+                            const bool nl_ = (bitl[u] & ~oldl[u]) != 0, nh_ = (bith[u] & ~oldh[u]) != 0;
+                            const unsigned long long ml = __ballot(nl_), mh = __ballot(nh_);
+                            const unsigned at = __builtin_amdgcn_mbcnt_hi((unsigned)(mh >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mh,
+                                                __builtin_amdgcn_mbcnt_hi((unsigned)(ml >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ml, (unsigned)n))));
+                            if (nl_) out[at] = (IT)c[u];
+                            if (nh_) out[at + (nl_ ? 1u : 0u)] = (IT)ch[u];
+                            n += __popcll(ml) + __popcll(mh);
+                        }
                         } else {
                         // test-and-set every chunk's columns (LDS atomics of one wave execute in issue
                         // order, so chunk u sees the bits of chunks < u whenever its result is read).  All
