@@ -964,12 +964,16 @@ __device__ __forceinline__ void smm_accumulate(const NumericArgs &A, double *__r
 #ifndef SMM_WIDE_CHUNKS
 #define SMM_WIDE_CHUNKS 1
 #endif
-#ifndef SMM_CH_UNROLL
-#define SMM_CH_UNROLL 8
+// Chunk loads per wave and round: 8 where the epilogue emits CSR, 4 where the tile goes to a dense row (measured
+// with 128-entry chunks: configs[1] 25.75 / 25.9 ms at 8 / 4, configs[2] 20.4 / 20.05, stage 1 of configs[3]
+// 19.8 / 18.6).  -DSMM_CH_UNROLL=n forces one value for both.
+#ifdef SMM_CH_UNROLL
+constexpr int CH_UNROLL_SPARSE = SMM_CH_UNROLL, CH_UNROLL_DENSE = SMM_CH_UNROLL;
+#else
+constexpr int CH_UNROLL_SPARSE = 8, CH_UNROLL_DENSE = 4;
 #endif
-constexpr int CH_UNROLL = SMM_CH_UNROLL;
 
-template <bool SYM, int NW>
+template <bool SYM, int NW, int CH_UNROLL>
 __device__ __forceinline__ void smm_accumulate_shared(const NumericArgs &A, double *__restrict__ acc, const int lo_c,
                                                       const int thresh, const int a0, const int a1, const int tc,
                                                       const int wave)
@@ -1140,7 +1144,7 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
                 smm_accumulate<SYM>(A, acc, scr + wave, (double *)(scr + NW), thresh, a0, a1, tc * NW + wave);
                 wait_lgkm0();                   // its hand-issued ds_add's (the compiler does not count them)
             }
-            else       smm_accumulate_shared<SYM, NW>(A, acc, lo_c, thresh, a0, a1, tc, wave);
+            else       smm_accumulate_shared<SYM, NW, (OUT == OUT_DENSE ? CH_UNROLL_DENSE : CH_UNROLL_SPARSE)>(A, acc, lo_c, thresh, a0, a1, tc, wave);
         }
     }
     if (NW > 1) __syncthreads();
