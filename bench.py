@@ -127,6 +127,203 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+def device_identity(torch, local):
+    """PCI bus id of this rank's GPU (the first RCCL run must show N distinct devices)."""
+    props = torch.cuda.get_device_properties(local)
+    try:
+        return f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}"
+    except AttributeError:
+        return str(getattr(props, "uuid", f"device{local}"))
+
+
+def run_config(cfg, args, env, steps, warmup, cpu_leg):
+    """Time `steps` passes of one BASELINE config (inputs generated on the device first, resident in HBM
+    before the timed region) and return the fields of its JSON line (rank 0; None elsewhere).  Every
+    buffer of the config is released before returning."""
+    torch, ctx, dist, smm_dist = env["torch"], env["ctx"], env["dist"], env["smm_dist"]
+    rank, world, device, rehearsal, tstream = env["rank"], env["world"], env["device"], env["rehearsal"], env["tstream"]
+    from sparse_matrix_mult_amd.synthetic import gen_csr_device, gen_symmetric_csr_device
+
+    if cfg == "c3":
+        n, k = int(20000 * args.scale), int(80000 * args.scale)
+        m, d = n, 0.02
+        A = ctx.csr_from_torch(n, k, *gen_csr_device(torch, n, k, 0.02, 3, device))                 # H
+        B = ctx.csr_from_torch(k, k, *gen_symmetric_csr_device(torch, k, 0.005, 4, device))         # Q
+        # rows of the result are split over the ranks by sum(n - i) (strong scaling of one product)
+        r0, r1 = smm_dist.triple_row_shards(n, world)[rank] if rank < n else (n, n)
+        out_buf = torch.empty((r1 - r0, n), dtype=torch.float64, device=device)
+        a_t = b_t = None
+    else:
+        if args.gather and not (args.rows or args.cols or args.density):
+            n, d = 200000, 0.001
+            m = n // world
+        elif cfg == "c4":
+            n, d = args.cols or 200000, args.density or 0.005
+            m = args.rows or n // 8                                 # one rank's share of the 8-way split
+        else:
+            n, d = args.cols or 50000, args.density or 0.01
+            m = args.rows or 50000
+        a_t = gen_csr_device(torch, m, n, d, 1 + 1000 * rank, device)      # rank's row block of A
+        b_t = gen_csr_device(torch, n, n, d, 2, device)                    # B, replicated
+        A = ctx.csr_from_torch(m, n, *a_t)
+        B = ctx.csr_from_torch(n, n, *b_t)
+        out_buf = torch.empty((m, n), dtype=torch.float64, device=device) if cfg == "c2" else None
+    nnz_a, nnz_b = A.nnz, B.nnz
+    gather_ev = []
+
+    def step():
+        if cfg == "c2":
+            ctx.dense_into(A, B, out_buf.data_ptr(), row_offset=rank * m, exact=args.exact)
+            return (out_buf,)
+        if cfg == "c3":
+            ctx.triple_into(A, B, out_buf.data_ptr(), row_begin=r0, row_end=r1, exact=args.exact)
+            return (out_buf,)
+        plan = ctx.spgemm_plan(A, B, row_offset=rank * m, exact=args.exact)
+        indptr = torch.empty(m + 1, dtype=torch.int64, device=device)
+        indices = torch.empty(plan.nnz, dtype=torch.int32, device=device)
+        data = torch.empty(plan.nnz, dtype=torch.float64, device=device)
+        plan.numeric_into(indptr.data_ptr(), indices.data_ptr(), data.data_ptr())
+        plan.close()
+        local_nnz = indices.numel()
+        if world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(tstream)
+            if args.gather:                                          # the whole C on every rank
+                indptr, indices, data = smm_dist.allgather_csr(indptr, indices, data, dist)
+            else:                                                    # the exchange step: global row pointer
+                indptr = smm_dist.global_indptr(indptr, dist, equal_rows=True)
+            e1.record(tstream)
+            gather_ev.append((e0, e1))
+        return indptr, indices, data, local_nnz
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        out = step()
+        del out
+    gather_ev.clear()
+    ctx.timing(True)
+    ctx.timing_reset()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    units = 0
+    keep_last = cpu_leg and world == 1 and cfg == "c1"       # rank 0 keeps the last result for the parity check
+    fence()
+    t0 = time.perf_counter()
+    marks[0].record(tstream)
+    for it in range(steps):
+        out = step()
+        units = out[3] if len(out) == 4 else out[0].numel()
+        marks[it + 1].record(tstream)
+        if it + 1 < steps or not keep_last:
+            del out
+    fence()
+    elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    ktimes = {k: ctx.kernel_time(k) for k in NUMERIC_KERNELS + ("smm_numeric_dense", "smm_numeric_hash", "smm_symbolic", "smm_symbolic_hash",
+                                                                 "smm_runs", "smm_triple_stage2")}
+    ctx.timing(False)
+    gather_ms = sum(a.elapsed_time(b) for a, b in gather_ev) / max(len(gather_ev), 1) if gather_ev else None
+
+    t = torch.tensor([elapsed, float(units)], dtype=torch.float64, device="cpu" if rehearsal else device)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, total_units = float(tmax[0]), float(t[1])
+    else:
+        total_units = float(units)
+
+    line = None
+    if rank == 0:
+        per_launch = lambda name: ktimes[name][0] / max(steps, 1)          # ms per step spent in that kernel
+        line = {
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3,
+            "ms_per_step_best": step_ms[0], "ms_per_step_median": step_ms[len(step_ms) // 2],
+            "higher_is_better": True, "scaling": "strong" if (args.gather or cfg == "c3") else "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+        }
+        if gather_ms is not None:
+            line["gather_ms" if args.gather else "exchange_ms"] = gather_ms      # the collective part of one step (rank 0)
+        mode = "SMM_EXACT (values bit-identical to the CPU loop)" if args.exact else "default (indices bit-exact, values to rounding)"
+        par = f"row-sharded x{world}" if world > 1 else "single GPU"
+        if cfg in ("c1", "c4"):
+            nnz_c = units
+            # SURVEY 8(d): compulsory one-touch bytes of one product
+            alg_bytes = (4 * (m + 1) + 12 * nnz_a) + (4 * (n + 1) + 12 * nnz_b) + (8 * (m + 1) + 12 * nnz_c)
+            num_ms = sum(per_launch(k) for k in NUMERIC_KERNELS)
+            # HBM traffic of the numeric phase, from the committed PMC passes of this same workload
+            # (rocprofv3 cannot run inside the bench; profiles/ says how it was taken)
+            traffic, traffic_src = None, None
+            ran = sorted(k for k in NUMERIC_KERNELS if per_launch(k) > 0)
+            for name in ("traffic_r3.json", "traffic_r2.json", "traffic_r1.json"):
+                try:
+                    tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+                    if (m, n, d) == (50000, 50000, 0.01) and not args.exact and not (args.lds_cols or args.waves or args.slab) \
+                            and sorted(tj.get("kernels", ["smm_numeric"])) == ran:
+                        traffic = tj["traffic_bytes_per_launch"]
+                        traffic_src = f"profiles/{name} (static: PMC passes of this workload and these kernels, not measured in this run)"
+                        break
+                except (OSError, ValueError, KeyError):
+                    pass
+            achieved = alg_bytes / (num_ms * 1e-3) / 1e9 if num_ms > 0 else 0.0
+            line.update({
+                "metric": "output nnz/sec, CSR x CSR -> CSR SpGEMM (first-touch order, float64)",
+                "value": total_units * steps / elapsed, "unit": "nnz/s",
+                "config": {"workload": f"{m}x{n} x {n}x{n} uniform random CSR d={d} -> CSR, per GPU "
+                                       f"(BASELINE configs[{1 if cfg == 'c1' else 4}]{', all-gatherv inside the step' if args.gather else ''})",
+                           "nnz_a": nnz_a, "nnz_b": nnz_b, "nnz_c_per_gpu": nnz_c, "mode": mode, "parallelism": par},
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                             "kernel": "numeric phase: " + " + ".join(k for k in NUMERIC_KERNELS if per_launch(k) > 0),
+                             "kernel_ms": num_ms,
+                             "kernels_ms": {k: per_launch(k) for k in ktimes if per_launch(k) > 0},
+                             "algorithmic_bytes": alg_bytes,
+                             # rate at which the phase moves its measured HBM-side traffic (PMC bytes / live duration)
+                             "traffic_rate_GBs": (traffic / (num_ms * 1e-3) / 1e9) if (traffic and num_ms > 0) else None,
+                             "whole_step_frac": alg_bytes / (step_ms[len(step_ms) // 2] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "symbolic_kernel_ms": per_launch("smm_symbolic")},
+            })
+            if keep_last:                                                 # the CPU leg runs at N = 1 only
+                line["cpu_baseline"] = cpu_baseline(torch, a_t, b_t, n, (out[0], out[1], out[2]))
+                del out
+        elif cfg == "c2":
+            alg_bytes = (4 * (m + 1) + 12 * nnz_a) + (4 * (n + 1) + 12 * nnz_b) + 8 * m * n
+            num_ms = per_launch("smm_numeric_dense") + per_launch("smm_dense_slab")
+            achieved = alg_bytes / (num_ms * 1e-3) / 1e9 if num_ms > 0 else 0.0
+            line.update({
+                "metric": "output elements/sec, CSR x CSR -> dense (float64)",
+                "value": total_units * steps / elapsed, "unit": "elements/s",
+                "config": {"workload": f"{m}x{n} x {n}x{n} uniform random CSR d={d} -> dense, per GPU (BASELINE configs[2])",
+                           "nnz_a": nnz_a, "nnz_b": nnz_b, "mode": mode, "parallelism": par},
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": num_ms,
+                             "kernels_ms": {k: per_launch(k) for k in ktimes if per_launch(k) > 0},
+                             "algorithmic_bytes": alg_bytes},
+            })
+        else:
+            nn, kk = A.rows, A.cols
+            fma = nnz_a * (nnz_b / kk) + nn * (nn + 1) / 2 * (nnz_a / nn)       # stage 1 products + stage 2 gather-FMAs
+            line.update({
+                "metric": "multiply-adds/sec, H Q H^T upper triangle (float64)",
+                "value": fma * steps / elapsed, "unit": "FMA/s",
+                "config": {"workload": f"H {nn}x{kk} d=0.02, Q {kk}x{kk} symmetric d~0.005 -> dense upper triangle "
+                                       f"(BASELINE configs[3])", "nnz_h": nnz_a, "nnz_q": nnz_b, "mode": mode, "parallelism": par},
+                "roofline": {"bound": "vector-fp64 / LDS gather (no MFMA: an indexing path)", "achieved": 2 * fma * steps / elapsed / 1e12,
+                             "peak": 78.6, "unit": "TFLOP/s", "frac": 2 * fma * steps / elapsed / 1e12 / 78.6, "traffic": None,
+                             "kernels_ms": {k: per_launch(k) for k in ktimes if per_launch(k) > 0}},
+            })
+    out = None
+    A.close(); B.close()
+    del a_t, b_t, out_buf
+    torch.cuda.empty_cache()
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,6 +346,8 @@ def main():
     ap.add_argument("--slab", type=str, default="", help="mode,ws,rows_per_wave of the row-block x column-slab kernels "
                                                          "(mode 0 auto / 1 off / 2 force; ws 0 = L2-sized)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="default run only: skip the short runs of the other BASELINE configs (extra_configs)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -177,7 +376,6 @@ def main():
 
     from sparse_matrix_mult_amd.engine import Context
     from sparse_matrix_mult_amd import distributed as smm_dist
-    from sparse_matrix_mult_amd.synthetic import gen_csr_device, gen_symmetric_csr_device
 
     # The library launches on torch's current stream (0 = the null stream -> SMM_STREAM_DEFAULT): the
     # generator's kernels, the product's kernels and the events below are all ordered on it.
@@ -190,171 +388,40 @@ def main():
     if args.slab:
         ctx.tune_slab(*[int(x) for x in args.slab.split(",")])
 
-    cfg = args.config
-    if cfg == "c3":
-        n, k = int(20000 * args.scale), int(80000 * args.scale)
-        m, d = n, 0.02
-        A = ctx.csr_from_torch(n, k, *gen_csr_device(torch, n, k, 0.02, 3, device))                 # H
-        B = ctx.csr_from_torch(k, k, *gen_symmetric_csr_device(torch, k, 0.005, 4, device))         # Q
-        # rows of the result are split over the ranks by sum(n - i) (strong scaling of one product)
-        r0, r1 = smm_dist.triple_row_shards(n, world)[rank] if rank < n else (n, n)
-        out_buf = torch.empty((r1 - r0, n), dtype=torch.float64, device=device)
-        a_t = b_t = None
-    else:
-        if args.gather and not (args.rows or args.cols or args.density):
-            n, d = 200000, 0.001
-            m = n // world
-        elif cfg == "c4":
-            n, d = args.cols or 200000, args.density or 0.005
-            m = args.rows or n // 8                                 # one rank's share of the 8-way split
-        else:
-            n, d = args.cols or 50000, args.density or 0.01
-            m = args.rows or 50000
-        a_t = gen_csr_device(torch, m, n, d, 1 + 1000 * rank, device)      # rank's row block of A
-        b_t = gen_csr_device(torch, n, n, d, 2, device)                    # B, replicated
-        A = ctx.csr_from_torch(m, n, *a_t)
-        B = ctx.csr_from_torch(n, n, *b_t)
-        out_buf = torch.empty((m, n), dtype=torch.float64, device=device) if cfg == "c2" else None
-    nnz_a, nnz_b = A.nnz, B.nnz
-
-    def step():
-        if cfg == "c2":
-            ctx.dense_into(A, B, out_buf.data_ptr(), row_offset=rank * m, exact=args.exact)
-            return (out_buf,)
-        if cfg == "c3":
-            ctx.triple_into(A, B, out_buf.data_ptr(), row_begin=r0, row_end=r1, exact=args.exact)
-            return (out_buf,)
-        plan = ctx.spgemm_plan(A, B, row_offset=rank * m, exact=args.exact)
-        indptr = torch.empty(m + 1, dtype=torch.int64, device=device)
-        indices = torch.empty(plan.nnz, dtype=torch.int32, device=device)
-        data = torch.empty(plan.nnz, dtype=torch.float64, device=device)
-        plan.numeric_into(indptr.data_ptr(), indices.data_ptr(), data.data_ptr())
-        plan.close()
-        local_nnz = indices.numel()
-        if world > 1:
-            if args.gather:                                          # the whole C on every rank
-                indptr, indices, data = smm_dist.allgather_csr(indptr, indices, data, dist)
-            else:                                                    # the exchange step: global row pointer
-                indptr = smm_dist.global_indptr(indptr, dist, equal_rows=True)
-        return indptr, indices, data, local_nnz
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        out = step()
-        del out
-    ctx.timing(True)
-    ctx.timing_reset()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    units = 0
-    fence()
-    t0 = time.perf_counter()
-    marks[0].record(tstream)
-    for it in range(args.steps):
-        out = step()
-        units = out[3] if len(out) == 4 else out[0].numel()
-        marks[it + 1].record(tstream)
-        if it + 1 < args.steps or args.no_cpu or world > 1 or cfg != "c1":
-            del out                               # rank 0 keeps the last result for the parity check
-    fence()
-    elapsed = time.perf_counter() - t0
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-    ktimes = {k: ctx.kernel_time(k) for k in NUMERIC_KERNELS + ("smm_numeric_dense", "smm_numeric_hash", "smm_symbolic", "smm_symbolic_hash",
-                                                                 "smm_runs", "smm_triple_stage2")}
-    ctx.timing(False)
-
-    t = torch.tensor([elapsed, float(units)], dtype=torch.float64, device="cpu" if rehearsal else device)
+    env = {"torch": torch, "ctx": ctx, "dist": dist, "smm_dist": smm_dist, "rank": rank, "world": world, "device": device,
+           "rehearsal": rehearsal, "tstream": tstream}
+    rccl = None
     if world > 1:
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed, total_units = float(tmax[0]), float(t[1])
-    else:
-        total_units = float(units)
+        # who is in the job: backend and the PCI bus id of every rank's GPU (N distinct devices expected)
+        ids = [None] * world
+        dist.all_gather_object(ids, device_identity(torch, local))
+        rccl = {"backend": dist.get_backend(), "world": world, "devices": ids, "distinct_devices": len(set(ids))}
 
+    line = run_config(args.config, args, env, args.steps, args.warmup, cpu_leg=not args.no_cpu)
+    if rank == 0 and rccl is not None:
+        line["rccl"] = rccl
+
+    # The default invocation (the driver's `python bench.py --gpus 1`) also times the other BASELINE configs, three
+    # steps each, in this same process: parity-test cases, reported next to the headline, never part of `value`.
+    default_run = (world == 1 and args.config == "c1" and not args.no_extra and not args.exact and not args.gather and
+                   not (args.rows or args.cols or args.density or args.lds_cols or args.waves or args.hash or args.slab))
+    if default_run:
+        extra = {}
+        for name, cfg in (("c2", "c2"), ("c3", "c3"), ("c4_share", "c4")):
+            t0 = time.perf_counter()
+            try:
+                r = run_config(cfg, args, env, 3, 1, cpu_leg=False)
+                extra[name] = {"ms_per_step": r["ms_per_step"], "ms_per_step_best": r["ms_per_step_best"], "metric": r["metric"],
+                               "value": r["value"], "unit": r["unit"], "workload": r["config"]["workload"],
+                               "roofline": {k: r["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernels_ms")},
+                               "wall_s_incl_input_generation": time.perf_counter() - t0}
+            except Exception as e:                           # the headline stands on its own
+                extra[name] = {"error": repr(e)}
+        line["extra_configs"] = extra
     if rank == 0:
-        per_launch = lambda name: ktimes[name][0] / max(args.steps, 1)          # ms per step spent in that kernel
-        line = {
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "ms_per_step_best": step_ms[0], "ms_per_step_median": step_ms[len(step_ms) // 2],
-            "higher_is_better": True, "scaling": "strong" if (args.gather or cfg == "c3") else "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-        }
-        mode = "SMM_EXACT (values bit-identical to the CPU loop)" if args.exact else "default (indices bit-exact, values to rounding)"
-        par = f"row-sharded x{world}" if world > 1 else "single GPU"
-        if cfg in ("c1", "c4"):
-            nnz_c = units
-            # compulsory one-touch bytes of one product
-            alg_bytes = (4 * (m + 1) + 12 * nnz_a) + (4 * (n + 1) + 12 * nnz_b) + (8 * (m + 1) + 12 * nnz_c)
-            num_ms = sum(per_launch(k) for k in NUMERIC_KERNELS)
-            # HBM traffic of the numeric phase, from the committed PMC passes of this same workload
-            # (rocprofv3 cannot run inside the bench; profiles/ says how it was taken)
-            traffic, traffic_src = None, None
-            ran = sorted(k for k in NUMERIC_KERNELS if per_launch(k) > 0)
-            for name in ("traffic_r2.json", "traffic_r1.json"):
-                try:
-                    tj = json.load(open(os.path.join(ROOT, "profiles", name)))
-                    if (m, n, d) == (50000, 50000, 0.01) and not args.exact and not (args.lds_cols or args.waves or args.slab) \
-                            and sorted(tj.get("kernels", ["smm_numeric"])) == ran:
-                        traffic = tj["traffic_bytes_per_launch"]
-                        traffic_src = f"profiles/{name} (static: PMC passes of this workload and these kernels, not measured in this run)"
-                        break
-                except (OSError, ValueError, KeyError):
-                    pass
-            achieved = alg_bytes / (num_ms * 1e-3) / 1e9 if num_ms > 0 else 0.0
-            line.update({
-                "metric": "output nnz/sec, CSR x CSR -> CSR SpGEMM (first-touch order, float64)",
-                "value": total_units * args.steps / elapsed, "unit": "nnz/s",
-                "config": {"workload": f"{m}x{n} x {n}x{n} uniform random CSR d={d} -> CSR, per GPU "
-                                       f"(BASELINE configs[{1 if cfg == 'c1' else 4}]{', all-gatherv inside the step' if args.gather else ''})",
-                           "nnz_a": nnz_a, "nnz_b": nnz_b, "nnz_c_per_gpu": nnz_c, "mode": mode, "parallelism": par},
-                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                             "kernel": "numeric phase: " + " + ".join(k for k in NUMERIC_KERNELS if per_launch(k) > 0),
-                             "kernel_ms": num_ms,
-                             "kernels_ms": {k: per_launch(k) for k in ktimes if per_launch(k) > 0},
-                             "algorithmic_bytes": alg_bytes,
-                             # rate at which the phase moves its measured HBM-side traffic (PMC bytes / live duration)
-                             "traffic_rate_GBs": (traffic / (num_ms * 1e-3) / 1e9) if (traffic and num_ms > 0) else None,
-                             "whole_step_frac": alg_bytes / (step_ms[len(step_ms) // 2] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "symbolic_kernel_ms": per_launch("smm_symbolic")},
-            })
-            if not args.no_cpu and world == 1 and cfg == "c1":           # the CPU leg runs at N = 1 only
-                line["cpu_baseline"] = cpu_baseline(torch, a_t, b_t, n, (out[0], out[1], out[2]))
-        elif cfg == "c2":
-            alg_bytes = (4 * (m + 1) + 12 * nnz_a) + (4 * (n + 1) + 12 * nnz_b) + 8 * m * n
-            num_ms = per_launch("smm_numeric_dense") + per_launch("smm_dense_slab")
-            achieved = alg_bytes / (num_ms * 1e-3) / 1e9 if num_ms > 0 else 0.0
-            line.update({
-                "metric": "output elements/sec, CSR x CSR -> dense (float64)",
-                "value": total_units * args.steps / elapsed, "unit": "elements/s",
-                "config": {"workload": f"{m}x{n} x {n}x{n} uniform random CSR d={d} -> dense, per GPU (BASELINE configs[2])",
-                           "nnz_a": nnz_a, "nnz_b": nnz_b, "mode": mode, "parallelism": par},
-                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": num_ms,
-                             "kernels_ms": {k: per_launch(k) for k in ktimes if per_launch(k) > 0},
-                             "algorithmic_bytes": alg_bytes},
-            })
-        else:
-            nn, kk = A.rows, A.cols
-            fma = nnz_a * (nnz_b / kk) + nn * (nn + 1) / 2 * (nnz_a / nn)       # stage 1 products + stage 2 gather-FMAs
-            line.update({
-                "metric": "multiply-adds/sec, H Q H^T upper triangle (float64)",
-                "value": fma * args.steps / elapsed, "unit": "FMA/s",
-                "config": {"workload": f"H {nn}x{kk} d=0.02, Q {kk}x{kk} symmetric d~0.005 -> dense upper triangle "
-                                       f"(BASELINE configs[3])", "nnz_h": nnz_a, "nnz_q": nnz_b, "mode": mode, "parallelism": par},
-                "roofline": {"bound": "vector-fp64 / LDS gather (no MFMA: an indexing path)", "achieved": 2 * fma * args.steps / elapsed / 1e12,
-                             "peak": 78.6, "unit": "TFLOP/s", "frac": 2 * fma * args.steps / elapsed / 1e12 / 78.6, "traffic": None,
-                             "kernels_ms": {k: per_launch(k) for k in ktimes if per_launch(k) > 0}},
-            })
         print(json.dumps(line), flush=True)
 
-    A.close(); B.close(); ctx.close()
+    ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

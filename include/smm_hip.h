@@ -33,7 +33,8 @@ enum smm_status {
     SMM_ERR_INVALID   = -2,   /* bad argument, shape mismatch, malformed CSR            */
     SMM_ERR_ALLOC     = -3,   /* hipMalloc / malloc failed                              */
     SMM_ERR_HIP       = -4,   /* a HIP runtime call or kernel launch failed             */
-    SMM_ERR_OVERFLOW  = -5    /* result does not fit the legacy int32 ABI               */
+    SMM_ERR_OVERFLOW  = -5,   /* result does not fit the legacy int32 ABI               */
+    SMM_ERR_UNSUPPORTED = -6  /* the device does not behave as SMM_EXACT needs (smm_ctx_exact_selftest) */
 };
 
 enum smm_flags {
@@ -98,6 +99,14 @@ int  smm_ctx_tune_slab(smm_ctx *ctx, int mode, int ws, int rows_per_wave);
  * B's column indices (cached on the operand) and 16-bit ordered lists: half the bytes of that phase's gather
  * and of the list traffic.  0: always int32.  Results are identical. */
 int  smm_ctx_tune_narrow(smm_ctx *ctx, int enable);
+/* Run-time guard of SMM_EXACT.  The exact walk adds the products of one wave-instruction that fall on the same
+ * accumulator in ascending lane order (the reference's order, src/sparsework.cpp:59-76) -- a property of
+ * gfx950's ds_add_f64 that was measured, not one the ISA promises.  This runs a sub-millisecond kernel that
+ * checks exactly that (random groupings of lanes on addresses, values of many magnitudes, compared bit for
+ * bit with the sum taken lane by lane) and fails with SMM_ERR_UNSUPPORTED where it does not hold.  Every
+ * context runs it by itself before its first SMM_EXACT product; inject_fault != 0 makes the check compare
+ * against the DESCENDING lane order instead, i.e. exercises the failure path (tests). */
+int  smm_ctx_exact_selftest(smm_ctx *ctx, int inject_fault);
 
 /* ------------------------------------------------------------------ operands
  * Replaces create_sparsemat + the three memmoves of csr_to_sparsemat
@@ -116,6 +125,23 @@ void smm_csr_destroy(smm_csr *m);
 int64_t smm_csr_rows(const smm_csr *m);
 int64_t smm_csr_cols(const smm_csr *m);
 int64_t smm_csr_nnz(const smm_csr *m);
+/* Values-only update of an operand whose sparsity pattern stays (the reference re-marshals all three arrays
+ * on every call, matrix_ops.py:187-202,339-340; the README's use case -- covariance products, README.md:5,13 --
+ * repeats one pattern with new values).  `data`: nnz doubles in HOST memory, copied over the operand's values
+ * in HBM; every cached copy that holds values (packed tile payload, slab-major copy, sliced-ELL copy of H) is
+ * refreshed in place, so plans made on this operand stay valid and smm_spgemm_numeric can simply be run
+ * again on them: a product with an unchanged pattern costs the numeric phase only.
+ * _device: the new values are already in HBM at d_data (copied, for operands made by smm_csr_from_host), or
+ * d_data is NULL / the operand's own borrowed array, which the caller has rewritten in place (operands made
+ * by smm_csr_from_device): only the cached copies are refreshed. */
+int  smm_csr_update_values(smm_ctx *ctx, smm_csr *m, const double *data);
+int  smm_csr_update_values_device(smm_ctx *ctx, smm_csr *m, const double *d_data);
+/* HBM held by the handle: its arrays (when owned) plus every cached copy. */
+int64_t smm_csr_device_bytes(const smm_csr *m);
+/* 64-bit content hash of a HOST buffer (no GPU involved): a chain of bijective mixing steps, so changing any
+ * one 8-byte word always changes the result; large buffers are hashed by several threads.  matrix_ops.py keys
+ * its operand cache on it -- a full-content check, so an operand edited in place is never served stale. */
+uint64_t smm_host_hash64(const void *p, int64_t bytes);
 /* 1 when every row has strictly increasing column indices (scipy "canonical" CSR). */
 int  smm_csr_is_canonical(smm_ctx *ctx, smm_csr *m);
 /* products[i] = sum over nonzeros (i,r) of A of nnz(B[r,:]) -- the work measure used to
@@ -147,6 +173,7 @@ int  smm_spgemm_numeric_host_i64(smm_ctx *ctx, smm_plan *plan,
 /* Only the int64 row pointer of the planned product (device->host, a.rows+1 entries). */
 int  smm_plan_indptr_host(smm_ctx *ctx, smm_plan *plan, int64_t *c_indptr);
 int64_t smm_plan_nnz(const smm_plan *plan);
+int64_t smm_plan_device_bytes(const smm_plan *plan);   /* HBM scratch the plan holds (lists, sub-run table, ...) */
 void smm_plan_destroy(smm_plan *plan);
 
 /* ------------------------------------------------------------------ CSR x CSR -> dense

@@ -20,6 +20,8 @@ SMM_SYMMETRIC = 1
 SMM_FULL_MATRIX = 2
 SMM_EXACT = 4
 SMM_MIRROR = 8
+SMM_ERR_ALLOC = -3
+SMM_ERR_UNSUPPORTED = -6
 
 _c_i64 = ctypes.c_int64
 _vp = ctypes.c_void_p
@@ -41,6 +43,7 @@ V2_PROTOTYPES = {
     "smm_ctx_tune_hash": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "smm_ctx_tune_slab": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "smm_ctx_tune_narrow": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "smm_ctx_exact_selftest": (ctypes.c_int, [_vp, ctypes.c_int]),
     "smm_csr_from_host": (ctypes.c_int, [_vp, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _pp]),
     "smm_csr_from_device": (ctypes.c_int, [_vp, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _pp]),
     "smm_csr_destroy": (None, [_vp]),
@@ -48,6 +51,10 @@ V2_PROTOTYPES = {
     "smm_csr_cols": (_c_i64, [_vp]),
     "smm_csr_nnz": (_c_i64, [_vp]),
     "smm_csr_is_canonical": (ctypes.c_int, [_vp, _vp]),
+    "smm_csr_update_values": (ctypes.c_int, [_vp, _vp, _vp]),
+    "smm_csr_update_values_device": (ctypes.c_int, [_vp, _vp, _vp]),
+    "smm_csr_device_bytes": (_c_i64, [_vp]),
+    "smm_host_hash64": (ctypes.c_uint64, [_vp, _c_i64]),
     "smm_row_products": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "smm_spgemm_symbolic": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _c_i64, _pp, ctypes.POINTER(_c_i64)]),
     "smm_spgemm_numeric": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
@@ -55,6 +62,7 @@ V2_PROTOTYPES = {
     "smm_spgemm_numeric_host_i64": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "smm_plan_indptr_host": (ctypes.c_int, [_vp, _vp, _vp]),
     "smm_plan_nnz": (_c_i64, [_vp]),
+    "smm_plan_device_bytes": (_c_i64, [_vp]),
     "smm_plan_destroy": (None, [_vp]),
     "smm_spgemm_dense": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _c_i64, _vp]),
     "smm_spgemm_dense_host": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _c_i64, _vp]),

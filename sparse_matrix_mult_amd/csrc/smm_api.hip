@@ -89,6 +89,7 @@ struct smm_ctx {
     static constexpr size_t PIN_BYTES = (size_t)32 << 20;
     void *pin[PIN_SLOTS] = {nullptr};
     hipEvent_t pin_ev[PIN_SLOTS] = {nullptr};
+    int exact_checked = 0;           // SMM_EXACT guard (smm_ctx_exact_selftest): 0 not run yet, 1 passed, -1 failed
     unsigned *d_flags = nullptr;     // [0] validation flags; +64: int -1 and +128: double 0 read by idle lanes
     std::recursive_mutex mu;         // every entry point that touches the context takes it: calls from
                                      // several host threads on one context serialise (one stream anyway)
@@ -334,6 +335,105 @@ extern "C" int smm_ctx_tune_shared(smm_ctx *c, int lds_cols, int waves)
     return SMM_OK;
 }
 
+// ------------------------------------------------------------------------------ SMM_EXACT guard
+extern "C" int smm_ctx_exact_selftest(smm_ctx *c, int inject_fault)
+{
+    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CTX_LOCK(c);
+    HIPCHK(hipSetDevice(c->device));
+    unsigned *d_bad = (unsigned *)((char *)c->d_flags + 240);
+    HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(unsigned), c->stream));
+    constexpr int NTRIAL = 16384;
+    LAUNCH(c, "smm_lds_order_selftest", smm_lds_order_selftest, 512, 64, 0, NTRIAL, inject_fault ? 1 : 0, d_bad);
+    LAUNCH_CHECK();
+    unsigned bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (bad)
+        return fail(SMM_ERR_UNSUPPORTED,
+                    "SMM_EXACT self-test failed: %u of %d accumulators differ from the lane-ordered sum%s -- this device does not "
+                    "apply the lanes of one ds_add_f64 in ascending lane order, so reference-order (bit-exact) accumulation is "
+                    "not available; run without SMM_EXACT (values agree to rounding)",
+                    bad, NTRIAL * 32, inject_fault ? " (fault injected)" : "");
+    return SMM_OK;
+}
+// every SMM_EXACT product goes through this first; the kernel runs once per context
+static int exact_guard(smm_ctx *c, int flags)
+{
+    if (!(flags & SMM_EXACT) || c->exact_checked > 0) return SMM_OK;
+    if (c->exact_checked == 0) {
+        const char *e = getenv("SMM_EXACT_INJECT_FAULT");
+        const int rc = smm_ctx_exact_selftest(c, e && *e && strcmp(e, "0") != 0);
+        if (rc != SMM_OK && rc != SMM_ERR_UNSUPPORTED) return rc;      // could not run: try again next time
+        c->exact_checked = rc == SMM_OK ? 1 : -1;
+        if (rc != SMM_OK) return rc;
+        return SMM_OK;
+    }
+    return fail(SMM_ERR_UNSUPPORTED, "SMM_EXACT is not available on this device (its self-test failed earlier on this context)");
+}
+
+// ------------------------------------------------------------------------------ host-side content hash
+// h' = rotl(h ^ w, 27) * P is a bijection of h for a fixed word and of the word for a fixed h: a buffer that
+// differs from another in one 8-byte word gives a different lane state from there on, whatever follows.
+// Blocks of 4 MB are hashed independently (four interleaved lanes each; by several threads when the buffer
+// is large) and their hashes are chained in order by the same step.
+static inline uint64_t hash_step(uint64_t h, uint64_t w)
+{
+    h ^= w;
+    h = (h << 27) | (h >> 37);
+    return h * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+}
+static inline uint64_t hash_final(uint64_t x)
+{
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+    return x;
+}
+static uint64_t hash_block(const unsigned char *p, size_t bytes)
+{
+    uint64_t h0 = 0x243F6A8885A308D3ull, h1 = 0x13198A2E03707344ull, h2 = 0xA4093822299F31D0ull, h3 = 0x082EFA98EC4E6C89ull;
+    size_t i = 0;
+    for (; i + 32 <= bytes; i += 32) {
+        uint64_t w0, w1, w2, w3;
+        memcpy(&w0, p + i, 8); memcpy(&w1, p + i + 8, 8); memcpy(&w2, p + i + 16, 8); memcpy(&w3, p + i + 24, 8);
+        h0 = hash_step(h0, w0); h1 = hash_step(h1, w1); h2 = hash_step(h2, w2); h3 = hash_step(h3, w3);
+    }
+    for (; i < bytes; i += 8) {                         // tail: whole words, the last one zero-padded
+        uint64_t w = 0;
+        memcpy(&w, p + i, std::min<size_t>(8, bytes - i));
+        h0 = hash_step(h0, w);
+    }
+    uint64_t h = hash_step(hash_step(hash_step(hash_step(0x452821E638D01377ull, h0), h1), h2), h3);
+    return hash_step(h, (uint64_t)bytes);
+}
+extern "C" uint64_t smm_host_hash64(const void *ptr, int64_t nbytes)
+{
+    if (!ptr || nbytes <= 0) return hash_final(0x9E3779B97F4A7C15ull);
+    const unsigned char *p = (const unsigned char *)ptr;
+    const size_t bytes = (size_t)nbytes;
+    constexpr size_t BLK = (size_t)4 << 20;
+    const size_t nblk = (bytes + BLK - 1) / BLK;
+    std::vector<uint64_t> hb(nblk);
+    auto run = [&](size_t b0, size_t stride) {
+        for (size_t b = b0; b < nblk; b += stride) hb[b] = hash_block(p + b * BLK, std::min(BLK, bytes - b * BLK));
+    };
+    unsigned nt = 1;
+    if (nblk >= 4) {
+        unsigned hw = std::thread::hardware_concurrency();
+        if (const char *e = getenv("SMM_HASH_THREADS")) hw = (unsigned)std::max(1, atoi(e));
+        nt = (unsigned)std::min<size_t>(std::min<unsigned>(hw ? hw : 1, 8), nblk);
+    }
+    if (nt <= 1) run(0, 1);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(run, (size_t)t, (size_t)nt);
+        run(0, nt);
+        for (auto &t : th) t.join();
+    }
+    uint64_t h = 0x3F84D5B5B5470917ull;
+    for (size_t b = 0; b < nblk; ++b) h = hash_step(h, hb[b]);
+    return hash_final(hash_step(h, (uint64_t)bytes));
+}
+
 // ------------------------------------------------------------------------------ result download
 // Device -> host copy of a result into the caller's (pageable, usually freshly allocated) array
 // (reference: sparsemat_to_csr / darray_to_numpy copy the result out, matrix_ops.py:205-240).  One big
@@ -456,9 +556,12 @@ struct smm_csr {
     std::vector<SlabCache> slabs;
     std::vector<PackCache> packs;
     unsigned short *idx16 = nullptr;             // 16-bit copy of idx (cols < 65535): the symbolic phase's gather stream
+    int *idx_pad = nullptr;                      // borrowed operands with >= 65535 columns: a copy of idx with two ints of slack (wide symbolic walk)
     // sliced-ELL copy for triple-product stage 2 (chunk width ell_chunk)
     int ell_chunk = 0, ell_nchunks = 0; bool ell_spread = false; int64_t *ell_off = nullptr;
     short *ell_col = nullptr; double *ell_val = nullptr;
+    int64_t ell_bytes = 0;                       // HBM of the ELL copy
+    int64_t derived_bytes = 0;                   // HBM of every other cached copy (tile indices, payloads, ...)
 };
 
 static int validate(smm_ctx *c, smm_csr *m)
@@ -499,7 +602,7 @@ extern "C" int smm_csr_from_host(smm_ctx *c, int64_t rows, int64_t cols, int64_t
     if (!indptr || (nnz > 0 && (!indices || !data))) return fail(SMM_ERR_INVALID, "NULL CSR array");
     int *dp = nullptr, *di = nullptr; double *dv = nullptr;
     if (hipMalloc((void **)&dp, (rows + 1) * sizeof(int)) != hipSuccess ||
-        hipMalloc((void **)&di, std::max<int64_t>(nnz, 1) * sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&di, (std::max<int64_t>(nnz, 1) + 2) * sizeof(int)) != hipSuccess ||     // + slack: the wide symbolic walk reads columns in pairs
         hipMalloc((void **)&dv, std::max<int64_t>(nnz, 1) * sizeof(double)) != hipSuccess) {
         (void)hipFree(dp); (void)hipFree(di); (void)hipFree(dv);
         return fail(SMM_ERR_ALLOC, "hipMalloc of a CSR operand failed");
@@ -547,7 +650,7 @@ extern "C" void smm_csr_destroy(smm_csr *m)
     for (auto &e : m->locs) (void)hipFree(e.loc);
     for (auto &e : m->slabs) { (void)hipFree(e.soff); (void)hipFree(e.scol); (void)hipFree(e.sval); }
     for (auto &e : m->packs) { (void)hipFree(e.desc); (void)hipFree(e.pay); }
-    (void)hipFree(m->idx16);
+    (void)hipFree(m->idx16); (void)hipFree(m->idx_pad);
     (void)hipFree(m->ell_off); (void)hipFree(m->ell_col); (void)hipFree(m->ell_val);
     delete m;
 }
@@ -560,6 +663,15 @@ extern "C" int smm_csr_is_canonical(smm_ctx *c, smm_csr *m)
     CTX_LOCK(c);
     CHK(validate(c, m));
     return (m->vflags & (CSR_UNSORTED | CSR_HAS_EQUAL)) ? 0 : 1;
+}
+
+extern "C" int64_t smm_csr_device_bytes(const smm_csr *m)
+{
+    if (!m) return -1;
+    CTX_LOCK(m->ctx);
+    int64_t own = 0;
+    if (m->owned) own = (m->rows + 1) * (int64_t)sizeof(int) + (std::max<int64_t>(m->nnz, 1) + 2) * (int64_t)sizeof(int) + std::max<int64_t>(m->nnz, 1) * (int64_t)sizeof(double);
+    return own + m->derived_bytes + m->ell_bytes;
 }
 
 // Tile geometry: nct coarse tiles of wc = nw*wf columns; fine tile t covers [t*wf,(t+1)*wf).
@@ -611,6 +723,7 @@ static int ensure_seg(smm_ctx *c, smm_csr *b, const Geom &g, const int **out)
         if (e != hipSuccess) { (void)hipFree(seg); return fail(SMM_ERR_HIP, "smm_segptr: %s", hipGetErrorString(e)); }
     }
     b->segs.push_back({g.wf, g.n_ft, seg});
+    b->derived_bytes += std::max<int64_t>(total, 1) * (int64_t)sizeof(int);
     *out = seg;
     return SMM_OK;
 }
@@ -627,6 +740,27 @@ static int ensure_idx16(smm_ctx *c, smm_csr *b)
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { (void)hipFree(b->idx16); b->idx16 = nullptr; return fail(SMM_ERR_HIP, "smm_idx16: %s", hipGetErrorString(e)); }
     }
+    b->derived_bytes += (std::max<int64_t>(b->nnz, 1) + 2) * (int64_t)sizeof(unsigned short);
+    return SMM_OK;
+}
+
+// The wide 32-bit symbolic walk loads columns in pairs, so the pair of a row's last, odd entry reaches one int
+// past the array.  Arrays this library allocated carry that slack; a BORROWED array (smm_csr_from_device) ends
+// where the caller's allocation may end, so the walk reads a padded copy of it instead (made once per handle).
+static int idx_with_slack(smm_ctx *c, smm_csr *b, const int **out)
+{
+    if (b->owned) { *out = b->idx; return SMM_OK; }
+    if (!b->idx_pad) {
+        const size_t n = (size_t)std::max<int64_t>(b->nnz, 1) + 2;
+        if (hipMalloc((void **)&b->idx_pad, n * sizeof(int)) != hipSuccess)
+            return fail(SMM_ERR_ALLOC, "hipMalloc of the padded column copy failed");
+        hipError_t e = hipMemsetAsync(b->idx_pad + (n - 2), 0, 2 * sizeof(int), c->stream);
+        if (e == hipSuccess && b->nnz > 0)
+            e = hipMemcpyAsync(b->idx_pad, b->idx, (size_t)b->nnz * sizeof(int), hipMemcpyDeviceToDevice, c->stream);
+        if (e != hipSuccess) { (void)hipFree(b->idx_pad); b->idx_pad = nullptr; return fail(SMM_ERR_HIP, "padded column copy: %s", hipGetErrorString(e)); }
+        b->derived_bytes += (int64_t)(n * sizeof(int));
+    }
+    *out = b->idx_pad;
     return SMM_OK;
 }
 
@@ -644,6 +778,7 @@ static int ensure_loc(smm_ctx *c, smm_csr *b, const Geom &g, const short **out)
         if (e != hipSuccess) { (void)hipFree(loc); return fail(SMM_ERR_HIP, "smm_loc16: %s", hipGetErrorString(e)); }
     }
     b->locs.push_back({g.wc, loc});
+    b->derived_bytes += std::max<int64_t>(b->nnz, 1) * (int64_t)sizeof(short);
     *out = loc;
     return SMM_OK;
 }
@@ -656,7 +791,7 @@ static int ensure_ell(smm_ctx *c, smm_csr *h, int nchunks, int chunk, bool sprea
     if (h->ell_val && h->ell_chunk == chunk && h->ell_nchunks == nchunks && h->ell_spread == spread) return SMM_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
     (void)hipFree(h->ell_off); (void)hipFree(h->ell_col); (void)hipFree(h->ell_val);
-    h->ell_off = nullptr; h->ell_col = nullptr; h->ell_val = nullptr; h->ell_chunk = 0;
+    h->ell_off = nullptr; h->ell_col = nullptr; h->ell_val = nullptr; h->ell_chunk = 0; h->ell_bytes = 0;
     Geom gh; gh.nw = 1; gh.nct = nchunks; gh.wf = chunk; gh.wc = chunk; gh.n_ft = nchunks;
     const int *hseg = nullptr;
     CHK(ensure_seg(c, h, gh, &hseg));
@@ -690,6 +825,7 @@ static int ensure_ell(smm_ctx *c, smm_csr *h, int nchunks, int chunk, bool sprea
     else LAUNCH(c, "smm_ell_fill", smm_ell_fill<2>, grid, 256, 0, E);
     LAUNCH_CHECK();
     h->ell_chunk = chunk; h->ell_nchunks = nchunks; h->ell_spread = spread;
+    h->ell_bytes = (items + 1) * (int64_t)sizeof(int64_t) + (total + WAVE) * (int64_t)(sizeof(short) + sizeof(double));
     return SMM_OK;
 }
 
@@ -820,6 +956,19 @@ extern "C" void smm_plan_destroy(smm_plan *p)
     delete p;
 }
 extern "C" int64_t smm_plan_nnz(const smm_plan *p) { return p ? p->nnz : -1; }
+extern "C" int64_t smm_plan_device_bytes(const smm_plan *p)
+{
+    if (!p) return -1;
+    smm_ctx *c = p->ctx;
+    CTX_LOCK(c);
+    int64_t total = 0;
+    const void *blocks[] = {p->d_ub_off, p->d_tmp, p->d_P, p->d_runs, p->d_rowcnt, p->d_cptr, p->d_lists, p->d_tail};
+    for (const void *b : blocks) {
+        auto it = c->live.find((void *)b);
+        if (b && it != c->live.end()) total += (int64_t)it->second;
+    }
+    return total;
+}
 
 // exclusive scan of n values into out[0..n] (out[n] = total)
 template <typename T>
@@ -885,6 +1034,7 @@ static int ensure_pack(smm_ctx *c, smm_csr *b, const Geom &g, smm_csr::PackCache
     pool_free(c, units); pool_free(c, off64);
     if (rc != SMM_OK) return rc;
     b->packs.push_back(e);
+    b->derived_bytes += std::max<int64_t>(cells, 1) * (int64_t)sizeof(int2) + std::max<int64_t>(total, 1) * (int64_t)sizeof(double);
     *out = e;
     return SMM_OK;
 }
@@ -954,8 +1104,81 @@ static int ensure_slab(smm_ctx *c, smm_csr *b, const SlabGeom &g, smm_csr::SlabC
     pool_free(c, cnt); pool_free(c, off64);
     if (rc != SMM_OK) { (void)hipFree(e.soff); (void)hipFree(e.scol); (void)hipFree(e.sval); return rc; }
     b->slabs.push_back(e);
+    b->derived_bytes += (cells + 1) * (int64_t)sizeof(int) + std::max<int64_t>(b->nnz, 1) * (int64_t)(sizeof(short) + sizeof(double));
     *out = e;
     return SMM_OK;
+}
+
+// ------------------------------------------------------------------------------ values-only update
+// New values on an unchanged pattern: the operand's value array is overwritten in place and every cached
+// copy that carries values is re-filled in place by the kernel that built it (same pattern -> same
+// positions), so the pointers plans hold stay valid.  Everything is queued on the context's stream, behind
+// whatever product is still running there.
+static int refresh_value_copies(smm_ctx *c, smm_csr *m)
+{
+    for (auto &e : m->packs) {
+        Geom gs; gs.nw = 1; gs.nct = e.nct; gs.wc = e.wc; gs.wf = e.wc; gs.n_ft = e.nct;
+        const int *seg = nullptr;
+        CHK(ensure_seg(c, m, gs, &seg));
+        if (m->rows > 0 && m->nnz > 0)
+            LAUNCH(c, "smm_pack_fill", smm_pack_fill, std::min<int64_t>((m->rows + 3) / 4, 65536), 256, 0, (int)m->rows, e.nct, e.wc, m->ptr,
+                   m->idx, m->val, seg, (const int2 *)e.desc, e.pay);
+    }
+    for (auto &e : m->slabs) {
+        Geom gs; gs.nw = 1; gs.nct = e.n_slabs; gs.wc = e.ws; gs.wf = e.ws; gs.n_ft = e.n_slabs;
+        const int *seg = nullptr;
+        CHK(ensure_seg(c, m, gs, &seg));
+        if (m->rows > 0 && m->nnz > 0)
+            LAUNCH(c, "smm_slab_fill", smm_slab_fill, std::min<int64_t>((m->rows + 3) / 4, 65536), 256, 0, (int)m->rows, e.n_slabs, e.ws,
+                   m->ptr, m->idx, m->val, seg, (const int *)e.soff, e.scol, e.sval);
+    }
+    if (m->ell_val) {
+        Geom gh; gh.nw = 1; gh.nct = m->ell_nchunks; gh.wf = m->ell_chunk; gh.wc = m->ell_chunk; gh.n_ft = m->ell_nchunks;
+        const int *hseg = nullptr;
+        CHK(ensure_seg(c, m, gh, &hseg));
+        EllArgs E{};
+        E.n = (int)m->rows; E.nchunks = m->ell_nchunks; E.chunk = m->ell_chunk; E.nslices = (int)((m->rows + WAVE - 1) / WAVE);
+        E.h_ptr = m->ptr; E.h_idx = m->idx; E.h_val = m->val; E.hseg = hseg;
+        E.cnt = nullptr; E.off = m->ell_off; E.col = m->ell_col; E.val = m->ell_val;
+        const int64_t items = (int64_t)E.nchunks * E.nslices;
+        const int grid = (int)((items + 3) / 4);
+        if (items > 0) {
+            if (m->ell_spread) LAUNCH(c, "smm_ell_fill", smm_ell_fill<1>, grid, 256, 0, E);
+            else LAUNCH(c, "smm_ell_fill", smm_ell_fill<2>, grid, 256, 0, E);
+        }
+    }
+    LAUNCH_CHECK();
+    return SMM_OK;
+}
+
+extern "C" int smm_csr_update_values(smm_ctx *c, smm_csr *m, const double *data)
+{
+    if (!c || !m) return fail(SMM_ERR_INVALID, "NULL argument");
+    if (m->ctx != c) return fail(SMM_ERR_INVALID, "operand belongs to another context");
+    CTX_LOCK(c);
+    HIPCHK(hipSetDevice(c->device));
+    if (!m->owned) return fail(SMM_ERR_INVALID, "smm_csr_update_values: the operand borrows its arrays (smm_csr_from_device); "
+                                                "rewrite them and call smm_csr_update_values_device");
+    if (m->nnz == 0) return SMM_OK;
+    if (!data) return fail(SMM_ERR_INVALID, "data is NULL");
+    HIPCHK(hipMemcpyAsync((void *)m->val, data, (size_t)m->nnz * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));          // the caller's host array may change as soon as this returns
+    return refresh_value_copies(c, m);
+}
+
+extern "C" int smm_csr_update_values_device(smm_ctx *c, smm_csr *m, const double *d_data)
+{
+    if (!c || !m) return fail(SMM_ERR_INVALID, "NULL argument");
+    if (m->ctx != c) return fail(SMM_ERR_INVALID, "operand belongs to another context");
+    CTX_LOCK(c);
+    HIPCHK(hipSetDevice(c->device));
+    if (m->nnz == 0) return SMM_OK;
+    if (d_data && d_data != m->val) {
+        if (!m->owned) return fail(SMM_ERR_INVALID, "smm_csr_update_values_device: a borrowed operand is updated by rewriting its "
+                                                    "own array (pass NULL or that array)");
+        HIPCHK(hipMemcpyAsync((void *)m->val, d_data, (size_t)m->nnz * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+    return refresh_value_copies(c, m);
 }
 
 // rows (a row list, or rows 0..m-1 of A) x all slabs -> `out`, rows of the launch ldo apart, column order
@@ -1032,6 +1255,7 @@ static int launch_symbolic_w(smm_ctx *c, smm_plan *p, int words, unsigned *gbm, 
     // LDS per wave: bitmap words + the guard word, or the hash slots
     const size_t lds = MARK == MARK_GLOBAL_BITMAP ? 0 : (size_t)(words + (MARK == MARK_LDS_HASH ? 0 : 1)) * wpb * sizeof(unsigned);
     auto kern = smm_symbolic<SYM, SAFE, MARK, UNROLL, I16>;
+    const int *b_idx32 = p->b->idx;
 #ifndef SMM_SYMW_UNROLL
 #define SMM_SYMW_UNROLL 4
 #endif
@@ -1040,18 +1264,18 @@ static int launch_symbolic_w(smm_ctx *c, smm_plan *p, int words, unsigned *gbm, 
 #endif
     if constexpr (!SAFE && MARK != MARK_LDS_HASH) {
         // chunks of 128 entries, two columns per lane (16-bit columns: the idle column must fit 16 bits)
-        // The pair of an odd chunk's last entry reaches one column past the row.  The 16-bit copy has slack for
-        // that; the caller's own 32-bit array is read one int past its end only if that int lies in the page
-        // of the last entry (a 4-byte read cannot leave a mapped page unless the array ends on a page boundary).
-        const bool tail_ok = I16 || (((uintptr_t)(p->b->idx + p->b->nnz)) & 4095u) != 0;
-        if (c->sym_wide && tail_ok && (!I16 || words * 32 + 31 <= 65535))
+        // The pair of an odd chunk's last entry reaches one column past the row: the 16-bit copy and the 32-bit
+        // arrays this library allocates have slack for that, a borrowed 32-bit array is read through a padded copy.
+        if (c->sym_wide && (!I16 || words * 32 + 31 <= 65535)) {
             kern = smm_symbolic<SYM, false, MARK, (UNROLL == 16 ? SMM_SYMW_UNROLL : SMM_SYMW_DEEP), I16, true>;
+            if (!I16) CHK(idx_with_slack(c, p->b, &b_idx32));
+        }
     }
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     LAUNCH(c, MARK == MARK_LDS_HASH ? "smm_symbolic_hash" : "smm_symbolic", kern, grid, wpb * 64, lds, (int)p->m, rowlist,
            d_nrows, p->row_offset, words, p->a->ptr, p->a->idx, p->b->ptr,
-           I16 ? (const void *)p->b->idx16 : (const void *)p->b->idx, p->d_ub_off, p->d_tmp, p->d_P,
+           I16 ? (const void *)p->b->idx16 : (const void *)b_idx32, p->d_ub_off, p->d_tmp, p->d_P,
            p->d_rowcnt, gbm, d_row_counter);
     LAUNCH_CHECK();
     return SMM_OK;
@@ -1066,6 +1290,7 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     CTX_LOCK(c);
     CHK(check_pair(c, a, b));
     if (a_row_offset < 0) return fail(SMM_ERR_INVALID, "negative a_row_offset");
+    CHK(exact_guard(c, flags));
     smm_plan *p = new smm_plan();
     p->ctx = c; p->a = a; p->b = b; p->flags = flags; p->row_offset = a_row_offset;
     p->m = a->rows; p->ncols = b->cols;
@@ -1209,6 +1434,9 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
                       slab_pays(c, a, p->sg, (double)p->n_bin[2] * (double)p->ncols, est_products, (double)p->nnz,
                                 (double)b->nnz / (double)std::max<int64_t>(b->rows, 1), (double)p->ncols);
         if (p->use_slab) PCHK(ensure_slab(c, b, p->sg, &p->slab));
+        // (chosen by the heuristic, not forced: the tile kernel's index is built as well, so that the numeric
+        // phase can fall back to it when the slab path's dense scratch does not fit)
+        if (p->use_slab && c->slab_mode == 2) { /* forced: slab only */ }
         else if (flags & SMM_EXACT) {
             PCHK(ensure_seg(c, b, p->g, &p->seg));
             PCHK(ensure_loc(c, b, p->g, &p->loc));
@@ -1293,8 +1521,13 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
         if (p->use_slab) {
             // values in column order into a dense scratch (one row per row of the bin), then the emission
             double *scratch = nullptr;
-            CHK(pool_get(c, (size_t)nd * (size_t)p->ncols, &scratch));
-            int rc = launch_slab<true>(c, p->a, p->b, p->slab, p->sg.rw, nd, dense_rows, sym, p->row_offset, scratch, p->ncols);
+            int rc = pool_get(c, (size_t)nd * (size_t)p->ncols, &scratch);
+            if (rc != SMM_OK) {
+                if (!(p->pack.pay || p->seg)) return rc;         // slab path forced: no tile index to fall back to
+                CHK(launch_numeric<OUT_SPARSE>(c, A, sym, p->g.nw, exact));
+                return SMM_OK;
+            }
+            rc = launch_slab<true>(c, p->a, p->b, p->slab, p->sg.rw, nd, dense_rows, sym, p->row_offset, scratch, p->ncols);
             if (rc == SMM_OK) {
                 A.c_dense = scratch; A.ldc = p->ncols;
                 A.dummy_idx = (const int *)((const char *)c->d_flags + 64);
@@ -1434,6 +1667,7 @@ extern "C" int smm_spgemm_dense(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, i
     if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
     CTX_LOCK(c);
     CHK(check_pair(c, a, b));
+    CHK(exact_guard(c, flags));
     if (!d_c && a->rows * b->cols > 0) return fail(SMM_ERR_INVALID, "d_c is NULL");
     if (flags & SMM_MIRROR) {
         if (!(flags & SMM_SYMMETRIC) || a->rows != b->cols || a_row_offset != 0)
@@ -1468,6 +1702,7 @@ extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags,
     if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
     CTX_LOCK(c);
     CHK(check_pair(c, h, q));
+    CHK(exact_guard(c, flags));
     const int64_t n = h->rows, K = h->cols;
     // the reference indexes temp_values[K] with Q's columns (sparse_sparse_dense.cpp:178,196): Q may
     // be K x c with c <= K (columns c..K-1 of T stay 0); c > K would write out of bounds there

@@ -171,6 +171,63 @@ __device__ __forceinline__ void glb_add(double *p, double x) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Run-time guard of SMM_EXACT (smm_ctx_exact_selftest).  The exact walk relies on two things: one wave's
+// ds_add_f64 instructions execute in issue order (the LDS is in order per wave), and inside ONE ds_add_f64 the
+// lanes that hit the same address are applied in ASCENDING LANE ORDER -- measured on gfx950
+// (scripts/ubench/lds_order.hip), not promised by the ISA.  Every trial throws the 64 lanes of a wave onto 1..32
+// accumulators at random (some lanes idle), twice in a row, with values spanning 60 binary orders of magnitude,
+// and compares each accumulator bit for bit with the sum taken lane by lane, instruction by instruction
+// (reference order: src/sparsework.cpp:59-76).  `descending` makes the expectation the reverse lane order:
+// the injected fault that exercises the failure path.  bad[0] counts the accumulators that differ.
+__device__ __forceinline__ unsigned st_hash(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ double st_value(unsigned h) {
+    const double u = (double)(h & 0xfffffu) / 1048576.0 - 0.5;
+    return ldexp(u, (int)((h >> 20) % 60u) - 30);
+}
+__global__ __launch_bounds__(64) void smm_lds_order_selftest(int ntrial, int descending, unsigned *__restrict__ bad)
+{
+    __shared__ double acc[32];
+    __shared__ double vals[2][WAVE];
+    __shared__ int addrs[2][WAVE];
+    const int lane = lane_id();
+    unsigned nbad = 0;
+    for (int t = blockIdx.x; t < ntrial; t += gridDim.x) {
+        const unsigned ht = st_hash(0x9e3779b9u * (unsigned)(t + 1));
+        const int spread = 1 + (int)(ht % 32u);
+        const double init = st_value(st_hash(ht ^ (0x1000u + (unsigned)lane)));
+        if (lane < 32) acc[lane] = init;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const unsigned h = st_hash(ht + 0x85ebca6bu * (unsigned)(2 * lane + k + 1));
+            addrs[k][lane] = (h % 8u == 0u) ? -1 : (int)((h >> 3) % (unsigned)spread);
+            vals[k][lane] = st_value(st_hash(h ^ 0xc2b2ae35u));
+        }
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < 2; ++k)                       // the instruction under test, as the exact walk issues it
+            lds_add_asm(lds_addr(acc) + 8u * (unsigned)(addrs[k][lane] >= 0 ? addrs[k][lane] : 0),
+                        addrs[k][lane] >= 0 ? vals[k][lane] : -0.0);
+        wait_lgkm0();
+        wave_sync();
+        if (lane < 32) {
+            double w = init;
+            for (int k = 0; k < 2; ++k)
+                for (int l = 0; l < WAVE; ++l) {
+                    const int src = descending ? WAVE - 1 - l : l;
+                    if (addrs[k][src] == lane) w += vals[k][src];
+                    else if (addrs[k][src] < 0 && lane == 0) w += -0.0;      // idle lanes add -0.0 to slot 0
+                }
+            if (__double_as_longlong(w) != __double_as_longlong(acc[lane])) ++nbad;
+        }
+        wave_sync();
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
+// ---------------------------------------------------------------------------------------
 // Operand validation: one wave per row.  Sets CSR_BAD for a non-monotone indptr or an index
 // outside [0, cols); CSR_UNSORTED / CSR_HAS_EQUAL describe the column order inside rows.
 // A malformed operand must never reach the compute kernels (an out-of-range column would be

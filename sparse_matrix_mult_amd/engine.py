@@ -81,6 +81,12 @@ class Context:
         """uint16 column stream / lists in the symbolic phase for operands with < 65535 columns (default on)."""
         check(self.lib, self.lib.smm_ctx_tune_narrow(self.handle, 1 if enable else 0))
 
+    def exact_selftest(self, inject_fault=False):
+        """Run the SMM_EXACT guard now (every context runs it by itself before its first exact product):
+        raises SmmError (code SMM_ERR_UNSUPPORTED) where the device does not add same-address lanes of one
+        ds_add_f64 in ascending lane order.  inject_fault=True exercises that failure path."""
+        check(self.lib, self.lib.smm_ctx_exact_selftest(self.handle, 1 if inject_fault else 0))
+
     def timing(self, enable=True):
         check(self.lib, self.lib.smm_ctx_timing(self.handle, 1 if enable else 0))
 
@@ -146,15 +152,9 @@ class Context:
         try:
             # nnz >= 2^31 (BASELINE configs[1]: 2.48e9): int64 column indices, like the row pointer -- scipy's
             # kernels take ONE index dtype per matrix; below that int32, as the reference returns
-            wide = plan.nnz > np.iinfo(np.int32).max if index_dtype is None else np.dtype(index_dtype) == np.int64
-            indptr = np.empty(a.rows + 1, dtype=np.int64)
-            indices = np.empty(plan.nnz, dtype=np.int64 if wide else np.int32)
-            data = np.empty(plan.nnz, dtype=np.float64)
-            fn = self.lib.smm_spgemm_numeric_host_i64 if wide else self.lib.smm_spgemm_numeric_host
-            check(self.lib, fn(self.handle, plan.handle, _ptr(indptr), _ptr(indices), _ptr(data)))
+            return plan.numeric_host(index_dtype)
         finally:
             plan.close()
-        return indptr, indices, data
 
     def spgemm_torch(self, a, b, symmetric=False, row_offset=0, exact=False):
         """Same product with the result left in HBM as torch tensors (indptr int64)."""
@@ -205,6 +205,23 @@ class DeviceCSR:
     def is_canonical(self):
         return bool(self.ctx.lib.smm_csr_is_canonical(self.ctx.handle, self.handle))
 
+    def update_values(self, data):
+        """New values on the same sparsity pattern (host array of nnz float64): the operand and every cached
+        copy are rewritten in place, plans made on it stay valid (smm_csr_update_values)."""
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        if data.size != self.nnz:
+            raise ValueError(f"update_values: {data.size} values for an operand with {self.nnz} nonzeros")
+        check(self.ctx.lib, self.ctx.lib.smm_csr_update_values(self.ctx.handle, self.handle, _ptr(data)))
+
+    def values_changed(self, d_ptr=None):
+        """The values in HBM were rewritten by the caller (borrowed operands: csr_from_torch), or are at device
+        pointer d_ptr (copied over the operand's own array): refresh the cached copies."""
+        check(self.ctx.lib, self.ctx.lib.smm_csr_update_values_device(self.ctx.handle, self.handle,
+                                                                      ctypes.c_void_p(d_ptr or 0)))
+
+    def device_bytes(self):
+        return int(self.ctx.lib.smm_csr_device_bytes(self.handle)) if self.handle else 0
+
     def close(self):
         if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
             self.ctx.lib.smm_csr_destroy(self.handle)
@@ -228,6 +245,21 @@ class Plan:
         out = np.empty(self.a.rows + 1, dtype=np.int64)
         check(self.ctx.lib, self.ctx.lib.smm_plan_indptr_host(self.ctx.handle, self.handle, _ptr(out)))
         return out
+
+    def device_bytes(self):
+        return int(self.ctx.lib.smm_plan_device_bytes(self.handle)) if self.handle else 0
+
+    def numeric_host(self, index_dtype=None):
+        """Run the numeric phase of this plan (again, after update_values on its operands if wanted) and return
+        (indptr int64, indices, data) as numpy arrays."""
+        ctx = self.ctx
+        wide = self.nnz > np.iinfo(np.int32).max if index_dtype is None else np.dtype(index_dtype) == np.int64
+        indptr = np.empty(self.a.rows + 1, dtype=np.int64)
+        indices = np.empty(self.nnz, dtype=np.int64 if wide else np.int32)
+        data = np.empty(self.nnz, dtype=np.float64)
+        fn = ctx.lib.smm_spgemm_numeric_host_i64 if wide else ctx.lib.smm_spgemm_numeric_host
+        check(ctx.lib, fn(ctx.handle, self.handle, _ptr(indptr), _ptr(indices), _ptr(data)))
+        return indptr, indices, data
 
     def numeric_into(self, d_indptr, d_indices, d_data):
         check(self.ctx.lib, self.ctx.lib.smm_spgemm_numeric(self.ctx.handle, self.handle, ctypes.c_void_p(d_indptr),

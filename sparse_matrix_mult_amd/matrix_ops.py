@@ -16,11 +16,12 @@ import collections
 import os
 import threading
 import weakref
-import zlib
+import ctypes
 
 import numpy as np
 from scipy.sparse import csr_matrix, isspmatrix_csr
 
+from ._lib import SMM_ERR_ALLOC, SmmError, SmmLibrary
 from .engine import default_context
 
 _INT32_MAX = np.iinfo(np.int32).max
@@ -57,76 +58,227 @@ def set_exact(flag):
 
 
 # ---------------------------------------------------------------------------------------------
-# Operand cache.  The reference's use case is many A against one B (README.md:5,13:
-# covariance matrices) and it re-marshals both operands on every call (matrix_ops.py:339-340).  Here
-# the last few uploaded CSR operands stay resident in HBM together with what the kernels derive from
-# them (validation, tile index, tile-local columns, the sliced-ELL copy of H): a repeated operand
-# skips the upload and all of that.  An entry is recognised by the IDENTITY of the caller's three
-# arrays -- the very same numpy objects, held by weak reference, so a freed array whose address is
-# re-used can never be mistaken for it -- and the shape, plus a checksum of a strided sample (<= 4096
-# elements of each array and both ends): replacing a matrix, or editing it anywhere the sample looks, is
-# seen; an in-place edit of a few entries between two calls may not be: call clear_cache() after
-# editing an operand in place, or switch the cache off (SMM_OPERAND_CACHE=0 / set_operand_cache(0)).
-_cache_lock = threading.Lock()
-_cache = collections.OrderedDict()          # key -> (DeviceCSR, weak references to the three arrays); most recently used last
+# Operand cache.  The reference re-marshals both operands from the caller's CURRENT arrays on
+# every call (matrix_ops.py:339-340, :187-202); its README's use case is many products on one sparsity
+# pattern (README.md:5,13: covariance matrices).  Here an uploaded operand stays resident in HBM together
+# with what the kernels derive from it (validation, tile index, packed payload, 16-bit columns, the
+# sliced-ELL copy of H), and the symbolic phase of a product stays resident as a plan:
+#   * an operand is recognised by the CONTENT of its three arrays -- a 64-bit hash of every byte
+#     (smm_host_hash64: a chain of bijective steps, so a change of any one element changes it), taken on
+#     every call.  An operand edited in place between two calls is therefore never served stale, and an
+#     equal matrix in other arrays is a hit.  Nothing is assumed from object identity;
+#   * same indptr/indices hashes, other data hash: only the values travel (smm_csr_update_values: the value
+#     array and the value halves of the cached copies are rewritten in place), and
+#   * a product whose two patterns and mode were seen before re-runs only the numeric phase of its cached
+#     plan: no smm_symbolic / smm_runs / smm_segptr launch at all.
+# Entries are dropped when the arrays they were made from have been garbage-collected, least recently used
+# first beyond SMM_OPERAND_CACHE entries (default 4; 0 = marshal afresh on every call, exactly as the
+# reference) or SMM_OPERAND_CACHE_GB of HBM (default 16; what the library reports for each handle and plan,
+# derived copies included), and all at once when an allocation fails (the product is then retried once).
+# pin_operand() is the explicit alternative: a handle the caller owns, no hashing at all.
+_cache_lock = threading.RLock()
+_cache = collections.OrderedDict()          # pattern key -> _Entry; most recently used last
+_plans = collections.OrderedDict()          # (pattern key A, pattern key B, symmetric, exact) -> _PlanEntry
 _cache_entries = int(os.environ.get("SMM_OPERAND_CACHE", "4"))
 _cache_max_bytes = int(float(os.environ.get("SMM_OPERAND_CACHE_GB", "16")) * (1 << 30))
+_plan_entries = int(os.environ.get("SMM_PLAN_CACHE", "2"))
+cache_stats = collections.Counter()         # 'upload', 'hit', 'values_update', 'plan_hit', 'plan_miss' (tests, diagnostics)
 
 
-def _sample(a):
-    n = a.size
-    if n <= 8192:
-        return zlib.crc32(np.ascontiguousarray(a).view(np.uint8))
-    step = n // 4096
-    return zlib.crc32(np.ascontiguousarray(a[::step]).view(np.uint8)) ^ zlib.crc32(np.ascontiguousarray(a[-64:]).view(np.uint8))
+def _hash(a):
+    a = np.ascontiguousarray(a)
+    return int(SmmLibrary().get_lib().smm_host_hash64(ctypes.c_void_p(a.ctypes.data), a.nbytes))
 
 
 def _operand_key(m):
-    parts = []
-    for a in (m.indptr, m.indices, m.data):
-        parts.append((a.__array_interface__["data"][0], a.size, a.dtype.str, _sample(a)))
-    return (m.shape, tuple(parts))
+    """(pattern key, data key) of a scipy CSR matrix: full-content hashes of indptr / indices and of data.
+    Any in-place edit of any element changes the part it belongs to."""
+    nnz = int(m.indptr[-1]) if len(m.indptr) else 0
+    idx, dat = m.indices[:nnz], m.data[:nnz]
+    pattern = (tuple(m.shape), nnz, m.indptr.dtype.str, idx.dtype.str, _hash(m.indptr), _hash(idx))
+    return pattern, (dat.dtype.str, _hash(dat))
 
 
-def _operand_bytes(h):
-    return 12 * h.nnz + 4 * (h.rows + 1)
+class _Entry:
+    __slots__ = ("handle", "pattern", "data_key", "users", "refs")
+
+    def __init__(self, handle, pattern, data_key):
+        self.handle, self.pattern, self.data_key, self.users, self.refs = handle, pattern, data_key, 0, []
+
+    def remember(self, arr):
+        self.refs = [r for r in self.refs if r() is not None]
+        if not any(r() is arr for r in self.refs):
+            try:
+                self.refs.append(weakref.ref(arr))
+            except TypeError:
+                pass
+
+    def orphaned(self):
+        return bool(self.refs) and all(r() is None for r in self.refs)
 
 
-def _upload(ctx, m):
-    """Device handle of a scipy CSR operand and whether the caller must close it (not cached)."""
+class _PlanEntry:
+    __slots__ = ("plan", "a", "b", "users")
+
+    def __init__(self, plan, a, b):
+        self.plan, self.a, self.b, self.users = plan, a, b, 0
+
+
+class _Lease:
+    """One call's hold on a device operand: .handle for the engine, .entry when it is a cache entry."""
+    __slots__ = ("handle", "entry", "_transient")
+
+    def __init__(self, handle, entry=None, transient=False):
+        self.handle, self.entry, self._transient = handle, entry, transient
+
+    def release(self):
+        if self.entry is not None:
+            with _cache_lock:
+                self.entry.users -= 1
+                if self.entry.users == 0 and self.entry.pattern in _cache:
+                    _trim_locked()               # what had to stay while it was in use may go now
+            self.entry = None
+        elif self._transient and self.handle is not None:
+            self.handle.close()
+        self.handle = None
+
+
+def _drop_entry_locked(key):
+    ent = _cache.pop(key, None)
+    if ent is None:
+        return
+    for pk in [pk for pk, pe in _plans.items() if pe.a is ent or pe.b is ent]:
+        _plans.pop(pk).plan.close()
+    ent.handle.close()
+
+
+def _cached_bytes_locked():
+    return sum(e.handle.device_bytes() for e in _cache.values()) + sum(pe.plan.device_bytes() for pe in _plans.values())
+
+
+def _trim_locked(keep=(), reserve=0):
+    """Enforce the limits (entries idle and not in `keep` only); reserve = entries about to be added."""
+    for key in [k for k, e in _cache.items() if e.users == 0 and e.orphaned() and e not in keep]:
+        _drop_entry_locked(key)                  # the arrays it was made from are gone
+
+    def idle_plan():
+        return next((k for k, pe in _plans.items() if pe.users == 0), None)
+
+    def idle_entry():
+        return next((k for k, e in _cache.items() if e.users == 0 and e not in keep), None)
+
+    while len(_plans) > max(_plan_entries, 0) and idle_plan() is not None:
+        _plans.pop(idle_plan()).plan.close()
+    while len(_cache) + reserve > _cache_entries and idle_entry() is not None:
+        _drop_entry_locked(idle_entry())
+    while _cached_bytes_locked() > _cache_max_bytes:
+        if idle_plan() is not None:              # plans (the symbolic phase's lists) go first
+            _plans.pop(idle_plan()).plan.close()
+        elif idle_entry() is not None:
+            _drop_entry_locked(idle_entry())
+        else:
+            break
+
+
+def _acquire(ctx, m):
+    """Device operand for one call (a _Lease).  m: scipy CSR matrix, or a PinnedOperand."""
+    if isinstance(m, PinnedOperand):
+        return m._lease(ctx)
     if _cache_entries <= 0:
-        return ctx.csr_from_scipy(m), True
-    key = _operand_key(m)
-    arrs = (m.indptr, m.indices, m.data)
+        cache_stats["upload"] += 1
+        return _Lease(ctx.csr_from_scipy(m), transient=True)
+    pattern, data_key = _operand_key(m)
     with _cache_lock:
-        hit = _cache.get(key)
-        if hit is not None:
-            h, refs = hit
-            if h.handle and h.ctx is ctx and all(r() is a for r, a in zip(refs, arrs)):
-                _cache.move_to_end(key)
-                return h, False
-            del _cache[key]                          # same address and sample, other arrays: a stale entry
+        ent = _cache.get(pattern)
+        if ent is not None and (not ent.handle.handle or ent.handle.ctx is not ctx):
+            _drop_entry_locked(pattern)
+            ent = None
+        if ent is not None:
+            if ent.data_key != data_key:
+                if ent.users > 0:                # another call is multiplying with the old values right now
+                    cache_stats["upload"] += 1
+                    return _Lease(ctx.csr_from_scipy(m), transient=True)
+                ent.handle.update_values(m.data[:ent.handle.nnz])
+                ent.data_key = data_key
+                cache_stats["values_update"] += 1
+            else:
+                cache_stats["hit"] += 1
+            ent.users += 1
+            ent.remember(m.data)
+            _cache.move_to_end(pattern)
+            _trim_locked(keep=(ent,))
+            return _Lease(ent.handle, entry=ent)
+        _trim_locked(reserve=1)                  # make room before the upload
     h = ctx.csr_from_scipy(m)
-    if _operand_bytes(h) > _cache_max_bytes:
-        return h, True
+    cache_stats["upload"] += 1
     with _cache_lock:
-        _cache[key] = (h, tuple(weakref.ref(a) for a in arrs))
-        _cache.move_to_end(key)
-        total = sum(_operand_bytes(v[0]) for v in _cache.values())
-        while len(_cache) > _cache_entries or total > _cache_max_bytes:
-            _, old = _cache.popitem(last=False)      # dropped here; freed when the last user lets go of it
-            total -= _operand_bytes(old[0])
-    return h, False
+        if pattern in _cache:                    # another thread was faster: use ours for this call only
+            return _Lease(h, transient=True)
+        ent = _Entry(h, pattern, data_key)
+        ent.users = 1
+        ent.remember(m.data)
+        _cache[pattern] = ent
+        _trim_locked(keep=(ent,))
+        if pattern not in _cache:                # does not fit the cache at all
+            ent.users = 0
+            return _Lease(h, transient=True)
+    return _Lease(h, entry=ent)
+
+
+def _plan_for(ctx, la, lb, symmetric, exact):
+    """(plan, release) for the product of two leased operands: the cached plan of this pair of patterns when
+    there is one (numeric phase only), else a fresh symbolic phase, cached when both operands are."""
+    key = None
+    if la.entry is not None and lb.entry is not None and _plan_entries > 0:
+        key = (la.entry.pattern, lb.entry.pattern, bool(symmetric), bool(exact))
+        with _cache_lock:
+            pe = _plans.get(key)
+            if pe is not None and pe.a is la.entry and pe.b is lb.entry and pe.plan.handle:
+                pe.users += 1
+                _plans.move_to_end(key)
+                cache_stats["plan_hit"] += 1
+                return pe.plan, lambda: _release_plan(pe)
+    cache_stats["plan_miss"] += 1
+    plan = ctx.spgemm_plan(la.handle, lb.handle, symmetric=symmetric, exact=exact)
+    if key is None:
+        return plan, plan.close
+    with _cache_lock:
+        old = _plans.pop(key, None)
+        if old is not None and old.users == 0:
+            old.plan.close()
+        pe = _PlanEntry(plan, la.entry, lb.entry)
+        pe.users = 1
+        _plans[key] = pe
+        _trim_locked(keep=(la.entry, lb.entry))
+    return plan, lambda: _release_plan(pe)
+
+
+def _release_plan(pe):
+    with _cache_lock:
+        pe.users -= 1
+        if pe.users == 0 and not any(v is pe for v in _plans.values()):
+            pe.plan.close()                      # evicted while in use
 
 
 def clear_cache():
-    """Forget every cached operand (their HBM is released as soon as no call is using them)."""
+    """Forget every cached operand and plan (their HBM is released; handles in use by a running call are
+    released when that call ends)."""
     with _cache_lock:
-        _cache.clear()
+        for pk in list(_plans):
+            pe = _plans.pop(pk)
+            if pe.users == 0:
+                pe.plan.close()
+        for key in list(_cache):
+            ent = _cache[key]
+            if ent.users == 0:
+                _drop_entry_locked(key)
+            else:
+                _cache.pop(key)                  # still leased: the last reference frees it (DeviceCSR.__del__)
 
 
 def set_operand_cache(entries):
-    """Number of operands kept resident between calls (0 switches the cache off); returns the old value."""
+    """Number of operands kept resident between calls (0 switches the cache off: every call marshals both
+    operands afresh, as the reference does); returns the old value."""
     global _cache_entries
     old, _cache_entries = _cache_entries, int(entries)
     if _cache_entries <= 0:
@@ -134,9 +286,52 @@ def set_operand_cache(entries):
     return old
 
 
+class PinnedOperand:
+    """An operand the caller keeps resident explicitly (no hashing, no look-up): pass it to
+    sparse_matrix_multiply() in place of the matrix.  update_values() replaces the values on the same
+    sparsity pattern; unpin() (or garbage collection) releases the HBM."""
+
+    def __init__(self, ctx, matrix):
+        matrix = _as_csr(matrix)
+        self.shape, self.nnz = tuple(matrix.shape), int(matrix.nnz)
+        self._ctx = ctx
+        self._handle = ctx.csr_from_scipy(matrix) if self.nnz else None
+        self._entry = _Entry(self._handle, ("pinned", id(self)), None)
+
+    def update_values(self, data):
+        if self._handle is not None:
+            self._handle.update_values(data)
+
+    def _lease(self, ctx):
+        if ctx is not self._ctx or self._handle is None or not self._handle.handle:
+            raise ValueError("PinnedOperand: unpinned, or pinned on another context")
+        with _cache_lock:
+            self._entry.users += 1
+        return _Lease(self._handle, entry=self._entry)
+
+    def unpin(self):
+        with _cache_lock:
+            for pk in [pk for pk, pe in _plans.items() if pe.a is self._entry or pe.b is self._entry]:
+                _plans.pop(pk).plan.close()
+        if self._handle is not None:
+            self._handle.close()
+        self._handle = None
+
+    def __del__(self):
+        try:
+            self.unpin()
+        except Exception:
+            pass
+
+
+def pin_operand(matrix):
+    """Upload `matrix` once and keep it (and everything derived from it) in HBM until unpin()."""
+    return PinnedOperand(default_context(), matrix)
+
+
 def _as_csr(x):
     # reference :307-310: anything csr_matrix() accepts; no sort, no dedup
-    return x if isspmatrix_csr(x) else csr_matrix(x)
+    return x if (isspmatrix_csr(x) or isinstance(x, PinnedOperand)) else csr_matrix(x)
 
 
 def _result_csr(indptr, indices, data, shape):
@@ -205,23 +400,37 @@ def sparse_matrix_multiply(matrix_a, matrix_b, output_format='sparse', symmetric
         return np.zeros(out_shape)
 
     ctx = default_context()
-    a, close_a = _upload(ctx, matrix_a)
-    b, close_b = _upload(ctx, matrix_b)
+
+    def product():
+        la = _acquire(ctx, matrix_a)
+        try:
+            lb = _acquire(ctx, matrix_b)
+            try:
+                a, b = la.handle, lb.handle
+                if use_triple_product:                           # reference :325-336
+                    mirror = compute_full_matrix == 'mirror' or (_full_symmetric and compute_full_matrix == 0)
+                    return ctx.triple_host(a, b, full=(compute_full_matrix == 1), exact=_exact, mirror=mirror)
+                if output_format == 'sparse':                    # reference :338-351
+                    plan, release = _plan_for(ctx, la, lb, bool(symmetric), _exact)
+                    try:
+                        indptr, indices, data = plan.numeric_host()
+                    finally:
+                        release()
+                    return _result_csr(indptr, indices, data, out_shape)
+                return ctx.dense_host(a, b, symmetric=bool(symmetric), exact=_exact,  # reference :353-365
+                                      mirror=bool(symmetric) and _full_symmetric)
+            finally:
+                lb.release()
+        finally:
+            la.release()
+
     try:
-        if use_triple_product:                               # reference :325-336
-            mirror = compute_full_matrix == 'mirror' or (_full_symmetric and compute_full_matrix == 0)
-            result = ctx.triple_host(a, b, full=(compute_full_matrix == 1), exact=_exact, mirror=mirror)
-        elif output_format == 'sparse':                      # reference :338-351
-            indptr, indices, data = ctx.spgemm_host(a, b, symmetric=bool(symmetric), exact=_exact)
-            result = _result_csr(indptr, indices, data, out_shape)
-        else:                                                # reference :353-365
-            result = ctx.dense_host(a, b, symmetric=bool(symmetric), exact=_exact,
-                                    mirror=bool(symmetric) and _full_symmetric)
-    finally:
-        if close_a:
-            a.close()
-        if close_b:
-            b.close()
+        result = product()
+    except SmmError as e:
+        if e.code != SMM_ERR_ALLOC or not (_cache or _plans):
+            raise
+        clear_cache()                                            # the resident operands / plans were in the way
+        result = product()
 
     if isinstance(result, np.ndarray):                       # reference :370-373
         # (the first row decides almost always; a full scan of a 20 GB result costs 0.7 s)

@@ -120,3 +120,46 @@ def test_dense_and_triple_row_blocks_allgather(world):
         ret = mgr.dict()
         mp.spawn(_dense_worker, args=(world, port, ret), nprocs=world, join=True)
         assert dict(ret) == {r: True for r in range(world)}
+
+
+def _few_rows_worker(rank, world, port, ret):
+    """Fewer rows than ranks: the trailing ranks own no row at all and send / receive nothing in the
+    variable-length all-gather (sizes 0), yet every rank ends with the whole CSR and the whole dense matrix."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle
+    from sparse_matrix_mult_amd.distributed import (allgather_csr, allgather_rows, allgatherv, balanced_row_shards,
+                                                    row_work, _shard_rows)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        A, B = rand_csr(2, 30, 0.4, 7), rand_csr(30, 25, 0.3, 8)
+        a, b = arrays(A), arrays(B)
+        shards = balanced_row_shards(row_work(a[0], a[1], np.diff(b[0])), world)
+        assert len(shards) == 2                                      # clamped to the rows, like limits()
+        r0, r1 = shards[rank] if rank < len(shards) else (2, 2)
+        cnt, idx, val = oracle.sparse_rows(a, b, 25, r0, r1)
+        indptr = torch.from_numpy(np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64))
+        g_ptr, g_idx, g_val = allgather_csr(indptr, torch.from_numpy(idx), torch.from_numpy(val), dist)
+        want = oracle.sparse(a, b, 25)
+        ok = np.array_equal(g_ptr.numpy(), want[0]) and np.array_equal(g_idx.numpy(), want[1]) and np.array_equal(g_val.numpy(), want[2])
+        flat, sizes = allgatherv(torch.from_numpy(val), dist)
+        ok &= sizes[-1] == 0 and sum(sizes) == len(want[2]) and np.array_equal(flat.numpy(), want[2])
+        blk = oracle.dense(a, b, 25, row_begin=r0, row_end=r1)
+        full = allgather_rows(torch.from_numpy(blk), _shard_rows(shards, world), dist).numpy()
+        ok &= np.array_equal(full, oracle.dense(a, b, 25))
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_more_ranks_than_rows_leaves_empty_shards():
+    import torch.multiprocessing as mp
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_few_rows_worker, args=(3, port, ret), nprocs=3, join=True)
+        assert dict(ret) == {0: True, 1: True, 2: True}

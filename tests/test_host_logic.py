@@ -76,3 +76,52 @@ def test_balanced_row_shards():
     loads = [w[b:e].sum() for b, e in sh]
     assert max(loads) / (sum(loads) / 4) < 1.1
     assert balanced_row_shards([], 4) == [(0, 0)]
+
+
+# ---- operand cache key (no GPU involved: smm_host_hash64 is host code)
+def test_operand_key_sees_every_single_element_edit():
+    """The reference marshals the caller's CURRENT arrays on every call (matrix_ops.py:339-340, :187-202); the
+    operand cache may therefore only recognise an operand whose every element is unchanged.  Its key is a
+    full-content hash: an in-place edit of ANY one element of indptr / indices / data changes the part of the
+    key it belongs to (the round-2 key, a strided sample, missed exactly these edits)."""
+    from sparse_matrix_mult_amd.matrix_ops import _operand_key
+    B = sp.random(5000, 5000, density=0.01, format="csr", random_state=np.random.default_rng(1))
+    assert B.nnz == 250000
+    pat0, dat0 = _operand_key(B)
+    assert _operand_key(B.copy()) == (pat0, dat0)                 # content, not identity
+    rng = np.random.default_rng(7)
+    for k in [12345, 0, B.nnz - 1] + rng.integers(0, B.nnz, 40).tolist():
+        old = B.data[k]
+        B.data[k] = np.nextafter(old, 2.0)                        # one ulp
+        pat, dat = _operand_key(B)
+        assert pat == pat0 and dat != dat0, k
+        B.data[k] = old
+    for k in [777, 0, B.nnz - 1] + rng.integers(0, B.nnz, 40).tolist():
+        old = B.indices[k]
+        B.indices[k] = old ^ 1
+        pat, dat = _operand_key(B)
+        assert pat != pat0 and dat == dat0, k
+        B.indices[k] = old
+    i = 2500
+    B.indptr[i] -= 1
+    assert _operand_key(B)[0] != pat0
+    B.indptr[i] += 1
+    assert _operand_key(B) == (pat0, dat0)
+    # swapping two elements (same multiset) is seen too: the hash is position-dependent
+    B.data[[10, 11]] = B.data[[11, 10]]
+    assert _operand_key(B)[1] != dat0
+
+
+def test_host_hash_is_the_same_for_every_thread_count_and_length_aware(monkeypatch):
+    import ctypes
+    from sparse_matrix_mult_amd._lib import SmmLibrary
+    lib = SmmLibrary().get_lib()
+    a = np.random.default_rng(3).integers(0, 255, 40 << 20, dtype=np.uint8)     # 10 blocks of 4 MB
+    h = lambda x: lib.smm_host_hash64(ctypes.c_void_p(x.ctypes.data), x.nbytes)
+    monkeypatch.setenv("SMM_HASH_THREADS", "1")
+    one = h(a)
+    monkeypatch.setenv("SMM_HASH_THREADS", "5")
+    assert h(a) == one
+    assert h(a[:-1]) != one and h(a[:1000]) != h(a[:1001])
+    z = np.zeros(64, np.uint8)
+    assert len({h(z[:n]) for n in range(1, 65)}) == 64                          # zero padding of the tail is not a collision
