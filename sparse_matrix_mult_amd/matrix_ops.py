@@ -156,16 +156,17 @@ def _cached_bytes_locked():
     return sum(e.handle.device_bytes() for e in _cache.values()) + sum(pe.plan.device_bytes() for pe in _plans.values())
 
 
-def _trim_locked(keep=(), reserve=0):
-    """Enforce the limits (entries idle and not in `keep` only); reserve = entries about to be added."""
-    for key in [k for k, e in _cache.items() if e.users == 0 and e.orphaned() and e not in keep]:
+def _trim_locked(keep=(), reserve=0, protect=()):
+    """Enforce the limits (entries idle and not in `keep` only); reserve = entries about to be added; protect =
+    pattern keys this call is about to look up (its other operand)."""
+    for key in [k for k, e in _cache.items() if e.users == 0 and e.orphaned() and e not in keep and k not in protect]:
         _drop_entry_locked(key)                  # the arrays it was made from are gone
 
     def idle_plan():
         return next((k for k, pe in _plans.items() if pe.users == 0), None)
 
     def idle_entry():
-        return next((k for k, e in _cache.items() if e.users == 0 and e not in keep), None)
+        return next((k for k, e in _cache.items() if e.users == 0 and e not in keep and k not in protect), None)
 
     while len(_plans) > max(_plan_entries, 0) and idle_plan() is not None:
         _plans.pop(idle_plan()).plan.close()
@@ -180,14 +181,15 @@ def _trim_locked(keep=(), reserve=0):
             break
 
 
-def _acquire(ctx, m):
-    """Device operand for one call (a _Lease).  m: scipy CSR matrix, or a PinnedOperand."""
+def _acquire(ctx, m, key=None, protect=()):
+    """Device operand for one call (a _Lease).  m: scipy CSR matrix, or a PinnedOperand; key = its
+    _operand_key when the caller has it already."""
     if isinstance(m, PinnedOperand):
         return m._lease(ctx)
     if _cache_entries <= 0:
         cache_stats["upload"] += 1
         return _Lease(ctx.csr_from_scipy(m), transient=True)
-    pattern, data_key = _operand_key(m)
+    pattern, data_key = key if key is not None else _operand_key(m)
     with _cache_lock:
         ent = _cache.get(pattern)
         if ent is not None and (not ent.handle.handle or ent.handle.ctx is not ctx):
@@ -206,9 +208,9 @@ def _acquire(ctx, m):
             ent.users += 1
             ent.remember(m.data)
             _cache.move_to_end(pattern)
-            _trim_locked(keep=(ent,))
+            _trim_locked(keep=(ent,), protect=protect)
             return _Lease(ent.handle, entry=ent)
-        _trim_locked(reserve=1)                  # make room before the upload
+        _trim_locked(reserve=1, protect=protect)     # make room before the upload
     h = ctx.csr_from_scipy(m)
     cache_stats["upload"] += 1
     with _cache_lock:
@@ -218,7 +220,7 @@ def _acquire(ctx, m):
         ent.users = 1
         ent.remember(m.data)
         _cache[pattern] = ent
-        _trim_locked(keep=(ent,))
+        _trim_locked(keep=(ent,), protect=protect)
         if pattern not in _cache:                # does not fit the cache at all
             ent.users = 0
             return _Lease(h, transient=True)
@@ -402,9 +404,13 @@ def sparse_matrix_multiply(matrix_a, matrix_b, output_format='sparse', symmetric
     ctx = default_context()
 
     def product():
-        la = _acquire(ctx, matrix_a)
+        # both keys first: looking A up must not evict the entry B is about to hit
+        cached = _cache_entries > 0
+        key_a = _operand_key(matrix_a) if cached and not isinstance(matrix_a, PinnedOperand) else None
+        key_b = _operand_key(matrix_b) if cached and not isinstance(matrix_b, PinnedOperand) else None
+        la = _acquire(ctx, matrix_a, key_a, protect=(key_b[0],) if key_b else ())
         try:
-            lb = _acquire(ctx, matrix_b)
+            lb = _acquire(ctx, matrix_b, key_b)
             try:
                 a, b = la.handle, lb.handle
                 if use_triple_product:                           # reference :325-336
