@@ -176,6 +176,19 @@ int64_t smm_plan_nnz(const smm_plan *plan);
 int64_t smm_plan_device_bytes(const smm_plan *plan);   /* HBM scratch the plan holds (lists, sub-run table, ...) */
 void smm_plan_destroy(smm_plan *plan);
 
+/* CSR mirror epilogue (not in the reference, opt-in): callers of symmetric=True get only i <= col
+ * (src/sparsework.cpp:217).  These two calls turn such an n x n upper-triangle CSR, resident in HBM, into the full
+ * symmetric matrix, in HBM: _symbolic writes the full row pointer (n+1 entries) and returns the full nnz, the
+ * caller allocates, _fill writes indices and values.  Order inside row i of the full matrix: first the mirrored
+ * entries (columns j < i) in ascending column order, then the row's own entries in the order the input holds them
+ * (the reference's first-touch order).  A row may receive at most 8192 mirrored entries (they are sorted in
+ * LDS); fuller results are refused with SMM_ERR_INVALID: there, symmetric=False is the cheaper way to the full
+ * matrix.  Entries left of the diagonal in the input are refused as well. */
+int  smm_csr_mirror_symbolic(smm_ctx *ctx, int64_t n, const int64_t *d_indptr, const int32_t *d_indices,
+                             int64_t *d_full_indptr, int64_t *nnz_full);
+int  smm_csr_mirror_fill(smm_ctx *ctx, int64_t n, const int64_t *d_indptr, const int32_t *d_indices, const double *d_data,
+                         const int64_t *d_full_indptr, int32_t *d_full_indices, double *d_full_data);
+
 /* ------------------------------------------------------------------ CSR x CSR -> dense
  * Replaces dense_nosym / dense_sym (src/sparse_sparse_dense.cpp:79-131 / :13-74).
  * d_c: a.rows x b.cols row-major float64 in HBM; every element is written (cells the

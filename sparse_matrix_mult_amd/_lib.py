@@ -64,6 +64,8 @@ V2_PROTOTYPES = {
     "smm_plan_nnz": (_c_i64, [_vp]),
     "smm_plan_device_bytes": (_c_i64, [_vp]),
     "smm_plan_destroy": (None, [_vp]),
+    "smm_csr_mirror_symbolic": (ctypes.c_int, [_vp, _c_i64, _vp, _vp, _vp, ctypes.POINTER(_c_i64)]),
+    "smm_csr_mirror_fill": (ctypes.c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "smm_spgemm_dense": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _c_i64, _vp]),
     "smm_spgemm_dense_host": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _c_i64, _vp]),
     "smm_triple_product": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _c_i64, _c_i64, _vp]),

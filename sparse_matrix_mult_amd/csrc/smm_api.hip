@@ -1695,6 +1695,79 @@ extern "C" int smm_spgemm_dense_host(smm_ctx *c, smm_csr *a, smm_csr *b, int fla
     return rc;
 }
 
+// ------------------------------------------------------------------------------ CSR mirror epilogue
+//  upper-triangle CSR in HBM -> full symmetric CSR in HBM, two calls: row pointer + nnz, then fill.
+extern "C" int smm_csr_mirror_symbolic(smm_ctx *c, int64_t n, const int64_t *d_indptr, const int32_t *d_indices,
+                                       int64_t *d_full_indptr, int64_t *nnz_full)
+{
+    if (!c || !d_indptr || !d_full_indptr || !nnz_full) return fail(SMM_ERR_INVALID, "NULL argument");
+    if (n < 0 || n >= INT32_MAX) return fail(SMM_ERR_INVALID, "bad dimension");
+    CTX_LOCK(c);
+    HIPCHK(hipSetDevice(c->device));
+    *nnz_full = 0;
+    if (n == 0) { HIPCHK(hipMemsetAsync(d_full_indptr, 0, sizeof(int64_t), c->stream)); return SMM_OK; }
+    int *mcnt = nullptr; int64_t *flen = nullptr;
+    CHK(pool_get(c, (size_t)n + 1, &mcnt));                       // [n] = longest mirrored segment
+    int rc = pool_get(c, (size_t)n, &flen);
+    if (rc != SMM_OK) { pool_free(c, mcnt); return rc; }
+    hipError_t e = hipMemsetAsync(mcnt, 0, ((size_t)n + 1) * sizeof(int), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_flags, 0, sizeof(unsigned), c->stream);
+    const int grid = (int)std::min<int64_t>((n + 3) / 4, 16384);
+    LAUNCH(c, "smm_mirror_count", smm_mirror_count, grid, 256, 0, (int)n, d_indptr, d_indices, mcnt, c->d_flags);
+    LAUNCH(c, "smm_mirror_rowlen", smm_mirror_rowlen, std::min<int64_t>((n + 255) / 256, 4096), 256, 0, (int)n, d_indptr, (const int *)mcnt,
+           flen, mcnt + n);
+    rc = scan_launch<int64_t>(c, n, flen, d_full_indptr);
+    unsigned bad = 0; int maxseg = 0;
+    if (rc == SMM_OK) {
+        if (e == hipSuccess) e = hipMemcpyAsync(nnz_full, d_full_indptr + n, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&bad, c->d_flags, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&maxseg, mcnt + n, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(SMM_ERR_HIP, "CSR mirror: %s", hipGetErrorString(e));
+    }
+    pool_free(c, mcnt); pool_free(c, flen);
+    if (rc != SMM_OK) return rc;
+    if (bad) return fail(SMM_ERR_INVALID, "CSR mirror: the input holds entries left of the diagonal or outside the n x n square");
+    if (maxseg > MIRROR_MAX_SEG)
+        return fail(SMM_ERR_INVALID, "CSR mirror: a row would receive %d mirrored entries (limit %d); for results this full compute the "
+                                     "product with symmetric=False instead", maxseg, MIRROR_MAX_SEG);
+    return SMM_OK;
+}
+
+extern "C" int smm_csr_mirror_fill(smm_ctx *c, int64_t n, const int64_t *d_indptr, const int32_t *d_indices, const double *d_data,
+                                   const int64_t *d_full_indptr, int32_t *d_full_indices, double *d_full_data)
+{
+    if (!c || !d_indptr || !d_full_indptr) return fail(SMM_ERR_INVALID, "NULL argument");
+    if (n <= 0) return SMM_OK;
+    CTX_LOCK(c);
+    HIPCHK(hipSetDevice(c->device));
+    if (!d_indices || !d_data || !d_full_indices || !d_full_data) return fail(SMM_ERR_INVALID, "NULL CSR array");
+    int *mcnt = nullptr, *cursor = nullptr;
+    CHK(pool_get(c, (size_t)n, &mcnt));
+    int rc = pool_get(c, (size_t)n, &cursor);
+    if (rc != SMM_OK) { pool_free(c, mcnt); return rc; }
+    hipError_t e = hipMemsetAsync(mcnt, 0, (size_t)n * sizeof(int), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(cursor, 0, (size_t)n * sizeof(int), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_flags, 0, sizeof(unsigned), c->stream);
+    const int grid = (int)std::min<int64_t>((n + 3) / 4, 16384);
+    LAUNCH(c, "smm_mirror_count", smm_mirror_count, grid, 256, 0, (int)n, d_indptr, d_indices, mcnt, c->d_flags);
+    LAUNCH(c, "smm_mirror_fill", smm_mirror_fill, grid, 256, 0, (int)n, d_indptr, d_indices, d_data, d_full_indptr, (const int *)mcnt, cursor,
+           d_full_indices, d_full_data);
+    LAUNCH(c, "smm_mirror_sort", smm_mirror_sort<false>, grid, 256, 0, (int)n, d_full_indptr, (const int *)mcnt, d_full_indices, d_full_data);
+    {
+        auto kern = smm_mirror_sort<true>;
+        const size_t lds = (size_t)MIRROR_MAX_SEG * (sizeof(double) + sizeof(int));
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        LAUNCH(c, "smm_mirror_sort", kern, std::min<int64_t>(n, (int64_t)c->n_cu * 4), 256, lds, (int)n, d_full_indptr, (const int *)mcnt,
+               d_full_indices, d_full_data);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);     // mcnt / cursor return to the pool
+    pool_free(c, mcnt); pool_free(c, cursor);
+    if (e != hipSuccess) return fail(SMM_ERR_HIP, "CSR mirror: %s", hipGetErrorString(e));
+    return SMM_OK;
+}
+
 // ------------------------------------------------------------------------------ triple product
 extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags, int64_t row_begin, int64_t row_end,
                                   double *d_c)

@@ -1954,4 +1954,127 @@ __global__ __launch_bounds__(256) void smm_mirror_upper(int n, double *__restric
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// CSR mirror epilogue (not in the reference, opt-in): an n x n result that holds only i <= col
+// (sparsework.cpp:217) becomes the full symmetric matrix, on the device.  Row i of the full matrix is
+//     [ the mirrored entries (i, j), j < i, in ASCENDING column order ]  followed by
+//     [ the row's own entries (i, col >= i) exactly as the upper result holds them: first-touch order ].
+// Three steps: count (one atomic per strictly-upper entry on its target row), fill (own entries copied behind
+// the space of the mirrored ones, mirrored ones dropped into it through a per-row cursor: arrival order), and a
+// sort of each row's mirrored segment by column, which makes the result deterministic.  The sort runs in LDS
+// (one wave per row up to 64 mirrored entries, one workgroup up to MIRROR_MAX_SEG); longer segments are refused:
+// for results that full a recomputation with symmetric=False is cheaper than any transposition.
+constexpr int MIRROR_MAX_SEG = 8192;
+
+__global__ __launch_bounds__(256) void smm_mirror_count(int n, const int64_t *__restrict__ uptr, const int *__restrict__ uidx,
+                                                        int *__restrict__ mcnt, unsigned *__restrict__ flags)
+{
+    const int lane = lane_id();
+    const int wpb = blockDim.x / WAVE;
+    unsigned bad = 0;
+    for (int i = blockIdx.x * wpb + (threadIdx.x >> 6); i < n; i += gridDim.x * wpb) {
+        for (int64_t k = uptr[i] + lane; k < uptr[i + 1]; k += WAVE) {
+            const int j = uidx[k];
+            if (j > i && j < n) atomicAdd(&mcnt[j], 1);
+            else if (j != i) bad = 1;                       // an entry left of the diagonal, or outside the square
+        }
+    }
+    if (bad) atomicOr(flags, 1u);
+}
+// full row lengths (for the scan) and the longest mirrored segment
+__global__ __launch_bounds__(256) void smm_mirror_rowlen(int n, const int64_t *__restrict__ uptr, const int *__restrict__ mcnt,
+                                                         int64_t *__restrict__ flen, int *__restrict__ maxseg)
+{
+    int mx = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        flen[i] = (int64_t)mcnt[i] + (uptr[i + 1] - uptr[i]);
+        mx = mcnt[i] > mx ? mcnt[i] : mx;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
+    if (lane_id() == 0 && mx > 0) atomicMax(maxseg, mx);
+}
+__global__ __launch_bounds__(256) void smm_mirror_fill(int n, const int64_t *__restrict__ uptr, const int *__restrict__ uidx,
+                                                       const double *__restrict__ uval, const int64_t *__restrict__ fptr,
+                                                       const int *__restrict__ mcnt, int *__restrict__ cursor,
+                                                       int *__restrict__ fidx, double *__restrict__ fval)
+{
+    const int lane = lane_id();
+    const int wpb = blockDim.x / WAVE;
+    for (int i = blockIdx.x * wpb + (threadIdx.x >> 6); i < n; i += gridDim.x * wpb) {
+        const int64_t s = uptr[i], own = fptr[i] + mcnt[i];
+        for (int64_t k = s + lane; k < uptr[i + 1]; k += WAVE) {
+            const int j = uidx[k];
+            const double v = uval[k];
+            fidx[own + (k - s)] = j;
+            fval[own + (k - s)] = v;
+            if (j > i) {
+                const int64_t at = fptr[j] + atomicAdd(&cursor[j], 1);
+                fidx[at] = i;
+                fval[at] = v;
+            }
+        }
+    }
+}
+// ascending-column sort of the mirrored segment of every row: bitonic network on (column, value) pairs.
+// LARGE = false: one wave per row, segments of 2..64 entries, exchanged by shuffles.
+// LARGE = true : one workgroup per row, segments of 65..MIRROR_MAX_SEG entries, in LDS.
+template <bool LARGE>
+__global__ __launch_bounds__(256) void smm_mirror_sort(int n, const int64_t *__restrict__ fptr, const int *__restrict__ mcnt,
+                                                       int *__restrict__ fidx, double *__restrict__ fval)
+{
+    extern __shared__ double srt_val[];
+    if constexpr (!LARGE) {
+        const int lane = lane_id();
+        const int wpb = blockDim.x / WAVE;
+        for (int i = blockIdx.x * wpb + (threadIdx.x >> 6); i < n; i += gridDim.x * wpb) {
+            const int len = mcnt[i];
+            if (len < 2 || len > WAVE) continue;
+            const int64_t b = fptr[i];
+            int key = lane < len ? fidx[b + lane] : 0x7fffffff;
+            double val = lane < len ? fval[b + lane] : 0.0;
+            for (int k = 2; k <= WAVE; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    const int pk = __shfl_xor(key, j);
+                    const double pv = __shfl_xor(val, j);
+                    const bool up = (lane & k) == 0, low = (lane & j) == 0;
+                    const bool take = (pk < key) == (up == low);          // lower lane of an ascending pair keeps the smaller key
+                    if (pk != key && take) { key = pk; val = pv; }
+                }
+            if (lane < len) { fidx[b + lane] = key; fval[b + lane] = val; }
+        }
+    } else {
+        int *srt_key = (int *)(srt_val + MIRROR_MAX_SEG);
+        for (int i = blockIdx.x; i < n; i += gridDim.x) {
+            const int len = mcnt[i];                                       // workgroup-uniform
+            if (len <= WAVE || len > MIRROR_MAX_SEG) continue;
+            const int64_t b = fptr[i];
+            int P = 128;
+            while (P < len) P <<= 1;
+            for (int x = threadIdx.x; x < P; x += blockDim.x) {
+                srt_key[x] = x < len ? fidx[b + x] : 0x7fffffff;
+                srt_val[x] = x < len ? fval[b + x] : 0.0;
+            }
+            __syncthreads();
+            for (int k = 2; k <= P; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int x = threadIdx.x; x < P; x += blockDim.x) {
+                        const int y = x ^ j;
+                        if (y > x) {
+                            const bool up = (x & k) == 0;
+                            const int kx = srt_key[x], ky = srt_key[y];
+                            if ((kx > ky) == up) {
+                                const double vx = srt_val[x];
+                                srt_key[x] = ky; srt_key[y] = kx;
+                                srt_val[x] = srt_val[y]; srt_val[y] = vx;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (int x = threadIdx.x; x < len; x += blockDim.x) { fidx[b + x] = srt_key[x]; fval[b + x] = srt_val[x]; }
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace smm

@@ -170,6 +170,43 @@ class Context:
             plan.close()
         return indptr, indices, data
 
+    def _dmalloc(self, nbytes):
+        p = ctypes.c_void_p()
+        check(self.lib, self.lib.smm_device_malloc(self.handle, int(nbytes), ctypes.byref(p)))
+        return p
+
+    def spgemm_host_mirrored(self, a, b, exact=False):
+        """The symmetric product's upper triangle (symmetric=True), mirrored on the device to the full symmetric
+        CSR (smm_csr_mirror_*).  Row i: mirrored entries (columns < i) in ascending column order, then the row's
+        own entries in first-touch order.  (indptr int64, indices int32, data float64) numpy arrays."""
+        if a.rows != b.cols:
+            raise ValueError("For symmetric output, the resulting matrix must be square.")
+        n = a.rows
+        plan = self.spgemm_plan(a, b, symmetric=True, exact=exact)
+        bufs = []
+        try:
+            up, ui, uv = (self._dmalloc(8 * (n + 1)), self._dmalloc(4 * max(plan.nnz, 1)), self._dmalloc(8 * max(plan.nnz, 1)))
+            bufs += [up, ui, uv]
+            plan.numeric_into(up.value, ui.value, uv.value)
+            fp = self._dmalloc(8 * (n + 1)); bufs.append(fp)
+            nnz = ctypes.c_int64()
+            check(self.lib, self.lib.smm_csr_mirror_symbolic(self.handle, n, up, ui, fp, ctypes.byref(nnz)))
+            if nnz.value > np.iinfo(np.int32).max:
+                raise SmmError(-5, "mirrored result has more than 2^31 nonzeros")
+            fi, fv = self._dmalloc(4 * max(nnz.value, 1)), self._dmalloc(8 * max(nnz.value, 1))
+            bufs += [fi, fv]
+            check(self.lib, self.lib.smm_csr_mirror_fill(self.handle, n, up, ui, uv, fp, fi, fv))
+            indptr = np.empty(n + 1, dtype=np.int64)
+            indices = np.empty(nnz.value, dtype=np.int32)
+            data = np.empty(nnz.value, dtype=np.float64)
+            for dst, src in ((indptr, fp), (indices, fi), (data, fv)):
+                check(self.lib, self.lib.smm_memcpy_d2h(self.handle, _ptr(dst), src, dst.nbytes))
+            return indptr, indices, data
+        finally:
+            plan.close()
+            for p in bufs:
+                self.lib.smm_device_free(self.handle, p)
+
     # ------------------------------------------------------------------ CSR x CSR -> dense
     def dense_host(self, a, b, symmetric=False, row_offset=0, exact=False, mirror=False):
         flags = _flags(symmetric, exact, mirror=mirror)

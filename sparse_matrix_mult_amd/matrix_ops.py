@@ -38,8 +38,10 @@ _exact = os.environ.get("SMM_EXACT", "0") not in ("", "0")
 # compute_full_matrix None/0 -- come back as the full symmetric matrix (lower triangle = mirror image of
 # the upper one, filled on the device).  compute_full_matrix='mirror' asks for the same for one triple
 # product.  The default stays the reference's behaviour (lower triangle 0.0), and compute_full_matrix=1
-# keeps reproducing the reference exactly (off-diagonal doubled).  CSR results are not
-# mirrored: a full CSR is what symmetric=False returns.
+# keeps reproducing the reference exactly (off-diagonal doubled).  CSR results (output_format='sparse',
+# symmetric=True) are mirrored too: row i of the full matrix holds the mirrored entries (columns < i) in ascending
+# column order, then the reference's upper-triangle row in its first-touch order; a row may receive at most 8192
+# mirrored entries (sorted in LDS) -- fuller results raise, there symmetric=False is the cheaper full matrix.
 _full_symmetric = False
 
 
@@ -416,6 +418,10 @@ def sparse_matrix_multiply(matrix_a, matrix_b, output_format='sparse', symmetric
                 if use_triple_product:                           # reference :325-336
                     mirror = compute_full_matrix == 'mirror' or (_full_symmetric and compute_full_matrix == 0)
                     return ctx.triple_host(a, b, full=(compute_full_matrix == 1), exact=_exact, mirror=mirror)
+                if output_format == 'sparse' and symmetric and _full_symmetric:
+                    # opt-in mirror epilogue: the full symmetric CSR (row i = mirrored entries in ascending column
+                    # order, then the reference's upper-triangle row in its first-touch order)
+                    return _result_csr(*ctx.spgemm_host_mirrored(a, b, exact=_exact), out_shape)
                 if output_format == 'sparse':                    # reference :338-351
                     plan, release = _plan_for(ctx, la, lb, bool(symmetric), _exact)
                     try:

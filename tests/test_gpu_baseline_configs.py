@@ -233,3 +233,33 @@ def test_legacy_abi_refuses_a_result_beyond_int32_loudly(c1, capfd):
     assert "2^31" in err or "int32" in err or "INT_MAX" in err or "overflow" in err.lower(), err
     for s in ops:
         lib.destroy_sparsemat(ctypes.byref(s))
+
+
+# ---------------------------------------------------------------------------------------------
+# configs[1] on the north star's LITERAL operands: scipy.sparse.random(50000, 50000, 0.01, random_state=
+# default_rng(1 | 2)) (SURVEY 8d's seeds: A = 1, B = 2), uploaded from the host like a caller's matrices.
+# Generation costs ~10 s per matrix on the host (sampling 2.5e7 of 2.5e9 cells without replacement) -- the
+# reason the other full-size cases draw their operands on the device (same distribution, other stream).
+def test_config1_on_literal_scipy_sparse_random_operands(ctx, oracle, tdev):
+    import time
+    from helpers import arrays
+    torch, dev = tdev
+    m = n = 50000
+    t0 = time.perf_counter()
+    A = sp.random(m, n, density=0.01, format="csr", random_state=np.random.default_rng(1), dtype=np.float64)
+    B = sp.random(n, n, density=0.01, format="csr", random_state=np.random.default_rng(2), dtype=np.float64)
+    print(f"scipy.sparse.random x2: {time.perf_counter() - t0:.1f} s")
+    assert A.nnz == B.nnz == 25000000 and A.has_sorted_indices and B.has_sorted_indices
+    a_h, b_h = arrays(A), arrays(B)
+    a, b = ctx.csr_from_scipy(A), ctx.csr_from_scipy(B)
+    try:
+        indptr, indices, data = ctx.spgemm_torch(a, b)
+        ctx.synchronize()
+    finally:
+        a.close(); b.close()
+    nnz = int(indptr[-1])
+    assert nnz > 2 ** 31 and abs(nnz / (m * n) - 0.99326) < 2e-4
+    for r0 in (7, 44444):
+        _check_sparse_sample(oracle, a_h, b_h, n, (indptr, indices, data), r0, r0 + 120, False)
+    lin = A @ (B @ np.ones(n))
+    assert rel_err(_row_sums(torch, indptr, data).cpu().numpy(), lin) <= LIN_RTOL
