@@ -61,7 +61,8 @@ def test_mirrored_csr_equals_the_full_product(oracle, make, exact):
         own = upper.indices[upper.indptr[r]:upper.indptr[r + 1]]
         k = len(row) - len(own)
         assert np.array_equal(row[k:], own) and (row[:k] < r).all() and (np.diff(row[:k]) > 0).all()
-        assert np.array_equal(full.data[full.indptr[r]:full.indptr[r + 1]][k:], upper.data[upper.indptr[r]:upper.indptr[r + 1]])
+        fo, uo = full.data[full.indptr[r]:full.indptr[r + 1]][k:], upper.data[upper.indptr[r]:upper.indptr[r + 1]]
+        assert np.array_equal(fo, uo) if exact else np.allclose(fo, uo, rtol=1e-10, atol=0)      # (two runs: default-mode sums differ in rounding)
     assert abs(full - full.T).nnz == 0                               # symmetric, value for value
 
 
