@@ -65,6 +65,7 @@ struct smm_ctx {
     bool own_stream = false;
     bool timing = false;
     int sym_wide = 1;        // symbolic phase on 16-bit columns: chunks of 128 entries (env SMM_SYM_WIDE=0: 64)
+    int sym_ccs = 1;         // symbolic phase over the chunk-padded column stream (smm_symbolic_ccs; env SMM_SYM_CCS=0: smm_symbolic)
     int s2_group = 5;        // triple stage 2: k-groups whose blocks follow each other on one XCD and share a tile of T
                              // through its L2 (env SMM_S2_GROUP; at BASELINE configs[3] 1: 58.2, 2: 56.3, 4: 60.1, 5: 54.8,
                              // 7: 54.9, 8: 58.9, 10: 54.8 ms -- powers of two lose, profiles/r2_s2_sweeps.txt)
@@ -187,6 +188,7 @@ extern "C" int smm_ctx_create(int device, void *hip_stream, smm_ctx **out)
     if (const char *e = getenv("SMM_NARROW_IDX")) c->narrow_idx = atoi(e) != 0;     // A/B switch (scripts/ab_env.sh)
     if (const char *e = getenv("SMM_S2_GROUP")) c->s2_group = std::max(1, atoi(e));
     if (const char *e = getenv("SMM_SYM_WIDE")) c->sym_wide = atoi(e) != 0;
+    if (const char *e = getenv("SMM_SYM_CCS")) c->sym_ccs = atoi(e) != 0;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hip_stream == SMM_STREAM_DEFAULT) { c->stream = nullptr; c->own_stream = false; }   // the device's null stream
     else if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
@@ -555,6 +557,9 @@ struct smm_csr {
     struct PackCache { int wc, nct; int2 *desc; double *pay; };   // packed tile-major payload (smm_pack_*)
     std::vector<SlabCache> slabs;
     std::vector<PackCache> packs;
+    // chunk-padded 16-bit column stream per column slab (smm_ccs_*): the symbolic phase's gather stream
+    struct CcsCache { int ws, n_slabs, bm_words, guard_chunk; int *cptr; unsigned short *stream; };
+    std::vector<CcsCache> ccs;
     unsigned short *idx16 = nullptr;             // 16-bit copy of idx (cols < 65535): the symbolic phase's gather stream
     int *idx_pad = nullptr;                      // borrowed operands with >= 65535 columns: a copy of idx with two ints of slack (wide symbolic walk)
     // sliced-ELL copy for triple-product stage 2 (chunk width ell_chunk)
@@ -650,6 +655,7 @@ extern "C" void smm_csr_destroy(smm_csr *m)
     for (auto &e : m->locs) (void)hipFree(e.loc);
     for (auto &e : m->slabs) { (void)hipFree(e.soff); (void)hipFree(e.scol); (void)hipFree(e.sval); }
     for (auto &e : m->packs) { (void)hipFree(e.desc); (void)hipFree(e.pay); }
+    for (auto &e : m->ccs) { (void)hipFree(e.cptr); (void)hipFree(e.stream); }
     (void)hipFree(m->idx16); (void)hipFree(m->idx_pad);
     (void)hipFree(m->ell_off); (void)hipFree(m->ell_col); (void)hipFree(m->ell_val);
     delete m;
@@ -1039,6 +1045,55 @@ static int ensure_pack(smm_ctx *c, smm_csr *b, const Geom &g, smm_csr::PackCache
     return SMM_OK;
 }
 
+// Chunk-padded 16-bit column stream of B for the symbolic walk (smm_ccs_* / smm_symbolic_ccs), cached per slab
+// geometry.  (Handed out BY VALUE, like the packed payload: the operand's vector may grow.)
+static int ensure_ccs(smm_ctx *c, smm_csr *b, int ws, int n_slabs, smm_csr::CcsCache *out)
+{
+    for (auto &e : b->ccs)
+        if (e.ws == ws && e.n_slabs == n_slabs) { *out = e; return SMM_OK; }
+    if (ws > CCS_MAX_WS) return fail(SMM_ERR_INVALID, "column slab wider than %d columns", CCS_MAX_WS);
+    Geom gs; gs.nw = 1; gs.nct = n_slabs; gs.wc = ws; gs.wf = ws; gs.n_ft = n_slabs;
+    const int *seg = nullptr;
+    CHK(ensure_seg(c, b, gs, &seg));
+    const int64_t cells = (int64_t)n_slabs * b->rows;
+    if (cells + n_slabs + 1 >= INT32_MAX) return fail(SMM_ERR_INVALID, "too many (slab, row) pieces");
+    int *chunks = nullptr; int64_t *off64 = nullptr;
+    CHK(pool_get(c, (size_t)std::max<int64_t>(cells, 1), &chunks));
+    int rc = pool_get(c, (size_t)cells + 1, &off64);
+    if (rc != SMM_OK) { pool_free(c, chunks); return rc; }
+    if (cells > 0) LAUNCH(c, "smm_ccs_count", smm_ccs_count, (cells + 255) / 256, 256, 0, (int)b->rows, n_slabs, seg, chunks);
+    rc = scan_launch<int>(c, cells, chunks, off64);
+    int64_t total = 0;
+    if (rc == SMM_OK) {
+        hipError_t e = hipMemcpyAsync(&total, off64 + cells, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(SMM_ERR_HIP, "chunked stream build: %s", hipGetErrorString(e));
+    }
+    if (rc == SMM_OK && total + 1 >= (INT32_MAX / CCS_CHUNK)) rc = fail(SMM_ERR_INVALID, "operand too large for the chunked column stream");
+    smm_csr::CcsCache e{ws, n_slabs, (ws + 31) / 32, (int)total, nullptr, nullptr};
+    const int64_t ptr_entries = (int64_t)n_slabs * (b->rows + 1);
+    if (rc == SMM_OK &&
+        (hipMalloc((void **)&e.cptr, (size_t)ptr_entries * sizeof(int)) != hipSuccess ||
+         hipMalloc((void **)&e.stream, (size_t)(total + 1) * CCS_CHUNK * sizeof(unsigned short)) != hipSuccess)) {
+        (void)hipFree(e.cptr); (void)hipFree(e.stream);
+        rc = fail(SMM_ERR_ALLOC, "hipMalloc of the chunked column stream failed");
+    }
+    if (rc == SMM_OK) {
+        LAUNCH(c, "smm_ccs_ptr", smm_ccs_ptr, (ptr_entries + 255) / 256, 256, 0, (int)b->rows, n_slabs, (const int64_t *)off64, e.cptr);
+        LAUNCH(c, "smm_ccs_fill", smm_ccs_fill, std::min<int64_t>(std::max<int64_t>((cells + 3) / 4, 1), 65536), 256, 0, (int)b->rows, n_slabs, ws,
+               e.bm_words, b->idx, seg, (const int *)e.cptr, e.stream);
+        hipError_t he = hipGetLastError();
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);        // chunks / off64 go back to the pool
+        if (he != hipSuccess) { (void)hipFree(e.cptr); (void)hipFree(e.stream); rc = fail(SMM_ERR_HIP, "chunked stream build: %s", hipGetErrorString(he)); }
+    }
+    pool_free(c, chunks); pool_free(c, off64);
+    if (rc != SMM_OK) return rc;
+    b->ccs.push_back(e);
+    b->derived_bytes += ptr_entries * (int64_t)sizeof(int) + (total + 1) * CCS_CHUNK * (int64_t)sizeof(unsigned short);
+    *out = e;
+    return SMM_OK;
+}
+
 // ------------------------------------------------------------------------------ row block x column slab path
 
 // Slab width: the slab's share of B's payload (10 bytes per entry) should sit in one XCD's 4 MiB L2 next
@@ -1394,7 +1449,33 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     // few waves per CU (wide bitmaps): a round is one memory round trip whatever it carries -> 32 loads in flight
     const bool deep = !safe && waves_per_cu <= 8;
     unsigned *gbm = nullptr;
-    if (nbm > 0) {
+    // Round 3: sorted B without repeated columns and 16-bit lists -> the walk over the chunk-padded stream
+    const bool use_ccs = c->sym_ccs && p->list16 && !safe && p->ncols <= CCS_MAX_WS && nbm > 0;
+    if (use_ccs) {
+        smm_csr::CcsCache cc{};
+        PCHK(ensure_ccs(c, b, (int)p->ncols, 1, &cc));
+        const size_t wave_bytes = (size_t)(cc.bm_words + WAVE) * sizeof(unsigned);
+        int cw = 4, best = 0;
+        for (int cand : {4, 2, 1}) {
+            const int waves = (int)std::min<size_t>(32, ((size_t)160 * 1024 / (cand * wave_bytes)) * cand);
+            if (waves > best) { best = waves; cw = cand; }
+        }
+        const size_t lds = wave_bytes * cw;
+        const int sgrid = (int)std::min<int64_t>((nbm + cw - 1) / cw, (int64_t)c->n_cu * 8 * (4 / cw));
+#ifndef SMM_CCS_UNROLL
+#define SMM_CCS_UNROLL 4
+#endif
+        auto kern = sym ? smm_symbolic_ccs<true, SMM_CCS_UNROLL> : smm_symbolic_ccs<false, SMM_CCS_UNROLL>;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e)); }
+        }
+        LAUNCH(c, "smm_symbolic", kern, sgrid, cw * 64, lds, (int)m, 1, bm_rows, bm_count, p->row_offset, cc.ws, cc.bm_words, (int)b->rows,
+               (int64_t)a->nnz, cc.guard_chunk, a->ptr, a->idx, (const int *)cc.cptr, (const unsigned short *)cc.stream,
+               (const int64_t *)p->d_ub_off, (unsigned short *)p->d_tmp, p->d_P, p->d_rowcnt, d_rowctr + 2);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "smm_symbolic_ccs: %s", hipGetErrorString(e)); }
+    } else if (nbm > 0) {
         int sgrid = (int)std::min<int64_t>((nbm + wpb - 1) / wpb, (int64_t)c->n_cu * 8 * (4 / wpb));
         if (!ldsbm) PCHK(pool_get(c, (size_t)sgrid * wpb * (bm_words + 1), &gbm));
         const int mark = ldsbm ? MARK_LDS_BITMAP : MARK_GLOBAL_BITMAP;
@@ -1798,7 +1879,7 @@ extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags,
     CHK(pool_get(c, (size_t)nr * K, &T));
     if (q->cols < K) HIPCHK(hipMemsetAsync(T, 0, (size_t)nr * K * sizeof(double), c->stream));
     smm_csr hv = *h;                       // row-range view of H (borrowed arrays)
-    hv.ptr = h->ptr + row_begin; hv.rows = nr; hv.owned = false; hv.segs.clear(); hv.locs.clear(); hv.slabs.clear(); hv.packs.clear(); hv.idx16 = nullptr;
+    hv.ptr = h->ptr + row_begin; hv.rows = nr; hv.owned = false; hv.segs.clear(); hv.locs.clear(); hv.slabs.clear(); hv.packs.clear(); hv.ccs.clear(); hv.idx16 = nullptr; hv.idx_pad = nullptr;
     // indptr of the view is not rebased: kernels only use ptr[row], ptr[row+1] as absolute positions.
     int rc = dense_into(c, &hv, q, flags & SMM_EXACT, 0, T, K);
     if (rc != SMM_OK) { pool_free(c, T); return rc; }

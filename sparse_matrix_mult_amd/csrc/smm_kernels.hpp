@@ -747,6 +747,213 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, const int *__restrict
 }
 
 // ---------------------------------------------------------------------------------------
+// Chunked column stream (CCS) of a sorted operand without repeated columns, and the symbolic walk over it
+// (round 3).  The columns of B are cut into n_slabs column slabs of ws <= 63 456 columns (one slab when B has
+// fewer columns than that); the piece of row j inside slab s is stored as slab-LOCAL 16-bit columns, padded to
+// whole chunks of 128 entries, chunk after chunk, 256-byte aligned:
+//     cptr[s * (rows + 1) + j]   first chunk of piece (s, j); the pieces of a slab follow each other in row order
+//     stream[chunk * 128 + p]    local column of entry p, or -- past the piece's end -- the guard column of lane p / 2
+// and ONE more chunk of guard columns only stands behind the last piece (the walk's dead slots load it),
+// so that a chunk is ONE unmasked 256-byte load (two whole cache lines, a dword = two columns per lane) and
+// needs no lane mask, no entry count and no EXEC set-up: the padding lanes carry guard columns, which live in 64
+// words of their own behind the wave's bitmap (all ones: never "new"; one word per lane: they do not collide on
+// one address as the single guard word of smm_symbolic's idle lanes does).
+constexpr int CCS_CHUNK = 128;
+constexpr int CCS_MAX_WS = 63456;            // (ws / 32 + 64 guard words) * 32 + 31 must fit 16 bits
+__host__ __device__ __forceinline__ int ccs_guard_col(int bm_words, int p) { return (bm_words + (p >> 1)) * 32 + 31; }
+
+__global__ __launch_bounds__(256) void smm_ccs_count(int rows, int n_slabs, const int *__restrict__ seg, int *__restrict__ chunks)
+{
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)rows * n_slabs) return;
+    const int s = (int)(gid / rows), j = (int)(gid % rows);
+    const int *sp = seg + (size_t)j * (n_slabs + 1) + s;
+    chunks[gid] = (sp[1] - sp[0] + CCS_CHUNK - 1) / CCS_CHUNK;
+}
+// cptr[s * (rows + 1) + j] from the exclusive scan of chunks[] (off64 has rows * n_slabs + 1 entries)
+__global__ __launch_bounds__(256) void smm_ccs_ptr(int rows, int n_slabs, const int64_t *__restrict__ off64, int *__restrict__ cptr)
+{
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)(rows + 1) * n_slabs) return;
+    const int s = (int)(gid / (rows + 1)), j = (int)(gid % (rows + 1));
+    cptr[gid] = (int)off64[(int64_t)s * rows + j];            // j == rows: the first chunk of the next slab = this slab's end
+}
+// one wave per (slab, row) piece
+__global__ __launch_bounds__(256) void smm_ccs_fill(int rows, int n_slabs, int ws, int bm_words, const int *__restrict__ idx,
+                                                    const int *__restrict__ seg, const int *__restrict__ cptr,
+                                                    unsigned short *__restrict__ stream)
+{
+    const int lane = lane_id();
+    const int wpb = blockDim.x / WAVE;
+    const int64_t npieces = (int64_t)rows * n_slabs;
+    if (blockIdx.x == 0 && threadIdx.x < CCS_CHUNK)              // the all-guard chunk behind the last piece
+        stream[(int64_t)cptr[(size_t)n_slabs * (rows + 1) - 1] * CCS_CHUNK + threadIdx.x] = (unsigned short)ccs_guard_col(bm_words, threadIdx.x);
+    for (int64_t it = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); it < npieces; it += (int64_t)gridDim.x * wpb) {
+        const int s = (int)(it / rows), j = (int)(it % rows);
+        const int *sp = seg + (size_t)j * (n_slabs + 1) + s;
+        const int k0 = sp[0], len = sp[1] - sp[0];
+        const int *cp = cptr + (size_t)s * (rows + 1) + j;
+        const int64_t base = (int64_t)cp[0] * CCS_CHUNK;
+        const int total = (cp[1] - cp[0]) * CCS_CHUNK;
+        for (int p = lane; p < total; p += WAVE)
+            stream[base + p] = (unsigned short)(p < len ? idx[k0 + p] - s * ws : ccs_guard_col(bm_words, p & (CCS_CHUNK - 1)));
+    }
+}
+// products of every (slab, row of A) unit: the capacity of its ordered list is min(products, slab columns that can appear)
+__global__ __launch_bounds__(256) void smm_ccs_row_work(int m, int n_slabs, int ws, int ncols, int rowsB, int64_t row_offset, int sym,
+                                                        const int *__restrict__ a_ptr, const int *__restrict__ a_idx,
+                                                        const int *__restrict__ seg, int64_t *__restrict__ ub)
+{
+    const int lane = lane_id();
+    const int wpb = blockDim.x / WAVE;
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < m; row += gridDim.x * wpb) {
+        for (int s = 0; s < n_slabs; ++s) {
+            int64_t t = 0;
+            for (int e = a_ptr[row] + lane; e < a_ptr[row + 1]; e += WAVE) {
+                const int *sp = seg + (size_t)a_idx[e] * (n_slabs + 1) + s;
+                t += sp[1] - sp[0];
+            }
+            for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+            if (lane == 0) {
+                const int64_t lo = (int64_t)s * ws;
+                int64_t cap = (ncols - lo) < ws ? (ncols - lo) : ws;
+                if (sym) { const int64_t gi = row + row_offset; const int64_t from = gi > lo ? gi : lo; cap = lo + cap > from ? lo + cap - from : 0; }
+                ub[(size_t)s * m + row] = t < cap ? t : cap;
+            }
+        }
+    }
+}
+
+// Symbolic walk over the chunked stream: the reference's first-touch rule (sparsework.cpp:70-110) for one
+// (slab, row) unit per wave -- with one slab that is smm_symbolic's job, output for output (tmp lists, P, row
+// counts), at two thirds of its instructions: per chunk one scalar-base load, two test-and-sets and the ordered
+// compaction; no mask, no count, no EXEC set-up around the load.
+//   unit u (handed out by a global counter, slab-major): slab s = u / nrows, row = rowlist[u % nrows]
+//   list_off[s * m + row]   where the unit's list starts in tmp (uint16, slab-local columns)
+//   P[s * nnzA + e]         list length of the unit when step e starts;  cnt[s * m + row] final length
+template <bool SYM, int UNROLL>
+__global__ __launch_bounds__(256) void smm_symbolic_ccs(int m, int n_slabs, const int *__restrict__ rowlist, const int *__restrict__ nrows_p,
+                                                        int64_t row_offset, int ws, int bm_words, int rowsB, int64_t nnzA, int guard_chunk,
+                                                        const int *__restrict__ a_ptr, const int *__restrict__ a_idx,
+                                                        const int *__restrict__ cptr, const unsigned short *__restrict__ stream,
+                                                        const int64_t *__restrict__ list_off, unsigned short *__restrict__ tmp,
+                                                        unsigned *__restrict__ P, int *__restrict__ cnt, int *__restrict__ unit_counter)
+{
+    extern __shared__ unsigned lds_bm[];
+    const int lane = lane_id();
+    const int lane4 = lane * 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nrows = nrows_p ? *nrows_p : m;
+    const int64_t nunits = (int64_t)nrows * n_slabs;
+    unsigned *bm = lds_bm + (size_t)wave * (bm_words + WAVE);
+    for (int w = lane; w < bm_words; w += WAVE) bm[w] = 0u;
+    bm[bm_words + lane] = 0xffffffffu;                          // the guard words: one per lane
+    const int guard = ccs_guard_col(bm_words, 2 * lane);        // this lane's guard column (never new)
+    for (;;) {
+        int ui = 0;
+        if (lane == 0) ui = atomicAdd(unit_counter, 1);
+        ui = rl(ui, 0);
+        if (ui >= nunits) break;
+        const int s = ui / nrows;
+        const int rr = ui - s * nrows;
+        const int row = rowlist ? rowlist[rr] : rr;
+        const int a0 = a_ptr[row], a1 = a_ptr[row + 1];
+        const int *__restrict__ cp = cptr + (size_t)s * (rowsB + 1);
+        int thresh = 0;                                         // SYM: slab-local columns below the diagonal are dropped
+        if (SYM) { const int64_t d = row + row_offset - (int64_t)s * ws; thresh = d < 0 ? 0 : (d > ws ? ws : (int)d); }
+        unsigned short *__restrict__ out = tmp + list_off[(size_t)s * m + row];
+        unsigned *__restrict__ Ps = P + (size_t)s * nnzA;
+        int n = 0;
+        if (a1 > a0) {
+            auto load_r = [&](int jb) { int e = jb + lane; e = e < a1 ? e : a1 - 1; return a_idx[e]; };
+            int r_c = load_r(a0), r_n = load_r(a0 + WAVE);
+            int cs = cp[r_c], ce = cp[r_c + 1];
+            for (int jb = a0; jb < a1; jb += WAVE) {
+                const int rem = a1 - jb;
+                const int nb = rem < WAVE ? rem : WAVE;
+                const int cs_n = cp[r_n], ce_n = cp[r_n + 1];      // next 64 entries' pieces
+                const int r_nn = load_r(jb + 2 * WAVE);            // A indices two batches ahead
+                unsigned myP = 0xffffffffu;                     // unset: entry without chunks
+                asm volatile("" : "+v"(cs), "+v"(ce));          // the wait for these loads sits here, once (see smm_symbolic)
+                const int nch = lane < nb ? ce - cs : 0;
+                const int incl = wave_scan_incl(nch);
+                const int excl = incl - nch;
+                const int T = rl(incl, WAVE - 1);
+                for (int tg = 0; tg < T; tg += WAVE) {
+                    // lane t - tg: descriptor of chunk t = its index in the stream (entry by binary search over the scan)
+                    const int t = tg + lane;
+                    int ej = 0;
+#pragma unroll
+                    for (int sft = WAVE / 2; sft > 0; sft >>= 1)
+                        if (__shfl(incl, ej + sft - 1) <= t) ej += sft;
+                    // (both shuffles OUTSIDE the select: inside it they would run under t < T only, and a lane whose
+                    // entry index ej lies beyond T -- empty pieces before it -- would read an inactive lane: 0)
+                    const int cs_e = __shfl(cs, ej), excl_e = __shfl(excl, ej);
+                    const int d_chunk = t < T ? cs_e + (t - excl_e) : guard_chunk;      // dead slots: guard columns only
+                    const int G = T - tg < WAVE ? T - tg : WAVE;
+                    int nrec = 0;                               // lane t - tg: length of the list before chunk t
+                    for (int rb = 0; rb < G; rb += UNROLL) {
+                        int c[UNROLL];
+#pragma unroll
+                        for (int u = 0; u < UNROLL; ++u) {          // all loads first; the chunk index is wave-uniform
+                            const unsigned short *cb = stream + (size_t)rl(d_chunk, rb + u) * CCS_CHUNK;
+                            asm volatile("global_load_dword %0, %1, %2" : "=v"(c[u]) : "v"(lane4), "s"(cb) : "memory");
+                        }
+                        unsigned oldl[UNROLL], oldh[UNROLL], bitl[UNROLL], bith[UNROLL];
+                        int ch[UNROLL];
+#pragma unroll
+                        for (int u = 0; u < UNROLL; ++u) {
+                            wait_vm(c[u], UNROLL - 1 - u);
+                            int lo = c[u] & 0xffff, hi = (int)((unsigned)c[u] >> 16);
+                            if (SYM) { lo = lo >= thresh ? lo : guard; hi = hi >= thresh ? hi : guard; }
+                            c[u] = lo; ch[u] = hi;
+                            bitl[u] = 1u << (lo & 31); bith[u] = 1u << (hi & 31);
+                            oldl[u] = atomicOr(bm + (lo >> 5), bitl[u]);
+                            oldh[u] = atomicOr(bm + (hi >> 5), bith[u]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < UNROLL; ++u) {          // consume strictly in order
+                            if (lane == rb + u) nrec = n;
+                            const bool nl_ = (bitl[u] & oldl[u]) == 0, nh_ = (bith[u] & oldh[u]) == 0;
+                            const unsigned long long ml = __ballot(nl_), mh = __ballot(nh_);
+                            const unsigned at = __builtin_amdgcn_mbcnt_hi((unsigned)(mh >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mh,
+                                                __builtin_amdgcn_mbcnt_hi((unsigned)(ml >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ml, (unsigned)n))));
+                            if (nl_) out[at] = (unsigned short)c[u];
+                            if (nh_) out[at + (nl_ ? 1u : 0u)] = (unsigned short)ch[u];
+                            n += __popcll(ml) + __popcll(mh);
+                        }
+                    }
+                    // P of the entries whose first chunk was in this group
+                    const int tl = excl - tg;
+                    const bool has = nch > 0 && tl >= 0 && tl < G;
+                    const int pv = __shfl(nrec, has ? tl : 0);
+                    if (has) myP = (unsigned)pv;
+                }
+                {   // an entry whose piece is empty starts where the next one starts
+                    unsigned v = myP;
+#pragma unroll
+                    for (int o = 1; o < WAVE; o <<= 1) {
+                        const unsigned y = __shfl_down(v, o);
+                        if (lane + o < WAVE && y < v) v = y;
+                    }
+                    if (v == 0xffffffffu) v = (unsigned)n;
+                    if (lane < nb) Ps[jb + lane] = v;
+                }
+                cs = cs_n; ce = ce_n; r_n = r_nn;
+            }
+        }
+        if (lane == 0) cnt[(size_t)s * m + row] = n;
+        // reset the marker for the next unit (sparsework.cpp:120-128: memset when the row is long, per entry otherwise)
+        if (n >= bm_words) {
+            for (int w = lane; w < bm_words; w += WAVE) bm[w] = 0;
+        } else {
+            for (int s2 = lane; s2 < n; s2 += WAVE) bm[out[s2] >> 5] = 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Sub-run table.  Step e of a row appended the columns list[P[e] .. P[e+1]) in ascending
 // order (B's rows are sorted), so the part that falls into coarse tile t is the contiguous
 // slot range [runs[e][t], runs[e][t+1]).  One wave per row, one lane per A entry, nct-1

@@ -508,8 +508,9 @@ def _mirror_api_checks(pkg, A, Q):
         D = pkg.sparse_matrix_multiply(A, A.T.tocsr(), output_format='dense', symmetric=True)
         assert np.array_equal(D, D.T) and np.allclose(D, (A @ A.T).toarray(), rtol=1e-10, atol=0)
         assert np.array_equal(pkg.sparse_matrix_multiply(A, Q, use_triple_product=True), full)
-        C = pkg.sparse_matrix_multiply(A, A.T.tocsr(), output_format='sparse', symmetric=True)   # CSR stays upper
-        assert (sp.tril(C, -1)).nnz == 0
+        C = pkg.sparse_matrix_multiply(A, A.T.tocsr(), output_format='sparse', symmetric=True)   # round 3: CSR is mirrored too
+        assert abs(C - C.T).nnz == 0 and np.allclose(C.toarray(), (A @ A.T).toarray(), rtol=1e-10, atol=0)
+        assert (sp.tril(C, -1)).nnz == (sp.triu(C, 1)).nnz > 0
     finally:
         pkg.set_full_symmetric(old)
     D = pkg.sparse_matrix_multiply(A, A.T.tocsr(), output_format='dense', symmetric=True)
