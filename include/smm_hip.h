@@ -99,6 +99,12 @@ int  smm_ctx_tune_slab(smm_ctx *ctx, int mode, int ws, int rows_per_wave);
  * B's column indices (cached on the operand) and 16-bit ordered lists: half the bytes of that phase's gather
  * and of the list traffic.  0: always int32.  Results are identical. */
 int  smm_ctx_tune_narrow(smm_ctx *ctx, int enable);
+/* The symbolic phase walks B as a chunk-padded stream of 16-bit columns, one column slab of at most
+ * max_slab_cols columns at a time (0 = the default, 63 456: products whose B has fewer columns are one slab).  A
+ * wider B is walked slab by slab -- every (slab, row) has its own ordered list, the numeric phase reads them
+ * through a table of (source, length, destination) sub-runs -- which keeps the marker bitmaps small (many waves
+ * per CU) and the lists 16-bit at any width.  Results do not depend on it, bit for bit. */
+int  smm_ctx_tune_symbolic(smm_ctx *ctx, int max_slab_cols);
 /* Run-time guard of SMM_EXACT.  The exact walk adds the products of one wave-instruction that fall on the same
  * accumulator in ascending lane order (the reference's order, src/sparsework.cpp:59-76) -- a property of
  * gfx950's ds_add_f64 that was measured, not one the ISA promises.  This runs a sub-millisecond kernel that

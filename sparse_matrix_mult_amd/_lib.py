@@ -44,6 +44,7 @@ V2_PROTOTYPES = {
     "smm_ctx_tune_slab": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "smm_ctx_tune_narrow": (ctypes.c_int, [_vp, ctypes.c_int]),
     "smm_ctx_exact_selftest": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "smm_ctx_tune_symbolic": (ctypes.c_int, [_vp, ctypes.c_int]),
     "smm_csr_from_host": (ctypes.c_int, [_vp, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _pp]),
     "smm_csr_from_device": (ctypes.c_int, [_vp, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _pp]),
     "smm_csr_destroy": (None, [_vp]),

@@ -66,6 +66,8 @@ struct smm_ctx {
     bool timing = false;
     int sym_wide = 1;        // symbolic phase on 16-bit columns: chunks of 128 entries (env SMM_SYM_WIDE=0: 64)
     int sym_ccs = 1;         // symbolic phase over the chunk-padded column stream (smm_symbolic_ccs; env SMM_SYM_CCS=0: smm_symbolic)
+    int sym_max_ws = 0;      // widest column slab of that walk (0 = CCS_MAX_WS); B with more columns is walked slab by slab
+                             // (smm_ctx_tune_symbolic; tests set it small to reach the slab path with small matrices)
     int s2_group = 5;        // triple stage 2: k-groups whose blocks follow each other on one XCD and share a tile of T
                              // through its L2 (env SMM_S2_GROUP; at BASELINE configs[3] 1: 58.2, 2: 56.3, 4: 60.1, 5: 54.8,
                              // 7: 54.9, 8: 58.9, 10: 54.8 ms -- powers of two lose, profiles/r2_s2_sweeps.txt)
@@ -320,6 +322,14 @@ extern "C" int smm_ctx_tune_narrow(smm_ctx *c, int enable)
     if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
     CTX_LOCK(c);
     c->narrow_idx = enable != 0;
+    return SMM_OK;
+}
+extern "C" int smm_ctx_tune_symbolic(smm_ctx *c, int max_slab_cols)
+{
+    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CTX_LOCK(c);
+    if (max_slab_cols < 0 || max_slab_cols > CCS_MAX_WS) return fail(SMM_ERR_INVALID, "slab width must be in [0,%d]", CCS_MAX_WS);
+    c->sym_max_ws = max_slab_cols;
     return SMM_OK;
 }
 extern "C" int smm_ctx_tune_shared(smm_ctx *c, int lds_cols, int waves)
@@ -868,16 +878,19 @@ extern "C" int smm_row_products(smm_ctx *c, const smm_csr *a, const smm_csr *b, 
 }
 
 // ------------------------------------------------------------------------------ numeric dispatch
-template <int OUT, bool SYM, int NW, bool EXACT, bool SCR = false, bool L16 = false>
+template <int OUT, bool SYM, int NW, bool EXACT, bool SCR = false, bool L16 = false, bool SLAB = false>
 static int launch_numeric_t(smm_ctx *c, NumericArgs &args)
 {
     if constexpr (OUT == OUT_SPARSE && !L16) {
         if (args.list16) return launch_numeric_t<OUT, SYM, NW, EXACT, SCR, true>(c, args);
     }
+    if constexpr (OUT == OUT_SPARSE && L16 && !SCR && !SLAB) {
+        if (args.runs2) return launch_numeric_t<OUT, SYM, NW, EXACT, false, true, true>(c, args);
+    }
     // accumulator tile (+ the exact walk's per-wave scratch behind it)
     // accumulators (+ the exact walk's per-wave scratch and the workgroup's 64-slot sink behind them)
     const size_t lds = (size_t)((args.wc + 1) & ~1) * sizeof(double) + (EXACT ? (size_t)NW * sizeof(ExactScratch) + 64 * sizeof(double) : 0);
-    auto kern = smm_numeric<OUT, SYM, NW, EXACT, SCR, L16>;
+    auto kern = smm_numeric<OUT, SYM, NW, EXACT, SCR, L16, SLAB>;
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t grid = (int64_t)args.m * args.nct;
@@ -921,6 +934,9 @@ static int launch_numeric(smm_ctx *c, NumericArgs &args, bool sym, int nw, bool 
     return fail(SMM_ERR_INVALID, "unsupported numeric configuration");
 }
 
+#ifndef SMM_CCS_UNROLL
+#define SMM_CCS_UNROLL 8        // chunk loads in flight per wave of smm_symbolic_ccs (configs[1]: 2: 6.7, 4: 5.5, 8: 5.2 ms)
+#endif
 // ------------------------------------------------------------------------------ CSR x CSR -> CSR
 struct SlabGeom { int ws, n_slabs, rw; };
 constexpr int SLAB_NW = 8;                       // waves per workgroup of smm_dense_slab
@@ -938,6 +954,11 @@ struct smm_plan {
     unsigned *d_P = nullptr;       // nnz(A)
     unsigned *d_runs = nullptr;    // nnz(A) x (nct+1)
     int2 *d_tail = nullptr;        // m: where the tail of every row starts (smm_runs)
+    // column slabs (B wider than one chunked-stream slab): slab-local lists, per-(slab,row) counts, smm_runs_slab's tables
+    int n_slabs = 1, tps = 0, ws = 0;
+    int *d_scnt = nullptr;         // n_slabs x m
+    unsigned *d_dst0 = nullptr;    // nnz(A)
+    uint2 *d_runs2 = nullptr;      // nct x nnz(A)
     const int *seg = nullptr;      // B's tile index and tile-local columns for geometry g (owned by b)
     const short *loc = nullptr;
     smm_csr::PackCache pack{0, 0, nullptr, nullptr};   // default mode: packed payload of B for geometry g
@@ -959,6 +980,7 @@ extern "C" void smm_plan_destroy(smm_plan *p)
     (void)hipStreamSynchronize(c->stream);
     pool_free(c, p->d_ub_off); pool_free(c, p->d_tmp); pool_free(c, p->d_P); pool_free(c, p->d_runs);
     pool_free(c, p->d_rowcnt); pool_free(c, p->d_cptr); pool_free(c, p->d_lists); pool_free(c, p->d_tail);
+    pool_free(c, p->d_scnt); pool_free(c, p->d_dst0); pool_free(c, p->d_runs2);
     delete p;
 }
 extern "C" int64_t smm_plan_nnz(const smm_plan *p) { return p ? p->nnz : -1; }
@@ -968,7 +990,8 @@ extern "C" int64_t smm_plan_device_bytes(const smm_plan *p)
     smm_ctx *c = p->ctx;
     CTX_LOCK(c);
     int64_t total = 0;
-    const void *blocks[] = {p->d_ub_off, p->d_tmp, p->d_P, p->d_runs, p->d_rowcnt, p->d_cptr, p->d_lists, p->d_tail};
+    const void *blocks[] = {p->d_ub_off, p->d_tmp, p->d_P, p->d_runs, p->d_rowcnt, p->d_cptr, p->d_lists, p->d_tail,
+                            p->d_scnt, p->d_dst0, p->d_runs2};
     for (const void *b : blocks) {
         auto it = c->live.find((void *)b);
         if (b && it != c->live.end()) total += (int64_t)it->second;
@@ -1404,6 +1427,111 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "row work: %s", hipGetErrorString(e)); }
     }
     pool_free(c, d_prod); pool_free(c, d_ub);
+    // Column slabs (round 3): B wider than one slab of the chunked stream (or than smm_ctx_tune_symbolic allows), sorted,
+    // without repeated columns, and most rows beyond the hash-set classes -> every (slab, row) is walked on its own.
+    {
+        const int ws_cap = c->sym_max_ws > 0 ? c->sym_max_ws : CCS_MAX_WS;
+        const bool wide = p->ncols > ws_cap && p->g.wc <= ws_cap && p->g.wc <= 32767;
+        const bool dominant = c->sym_max_ws > 0 || hmax1 == 0 || 2 * (int64_t)sbin[2] >= m;
+        if (c->sym_ccs && c->narrow_idx && wide && dominant && !safe && p->b_sorted && c->slab_mode != 2) {
+            if (d_slists) pool_free(c, d_slists);
+            const int tps = std::max(1, std::min(8, ws_cap / p->g.wc));
+            p->tps = tps; p->ws = tps * p->g.wc; p->n_slabs = (p->g.nct + tps - 1) / tps;
+            p->list16 = true;
+            const int ns = p->n_slabs;
+            smm_csr::CcsCache cc{};
+            PCHK(ensure_ccs(c, b, p->ws, ns, &cc));
+            Geom gs; gs.nw = 1; gs.nct = ns; gs.wc = p->ws; gs.wf = p->ws; gs.n_ft = ns;
+            const int *sseg = nullptr;
+            PCHK(ensure_seg(c, b, gs, &sseg));
+            // capacities and offsets of the (slab, row) lists
+            int64_t *d_ubs = nullptr;
+            PCHK(pool_get(c, (size_t)ns * m, &d_ubs));
+            pool_free(c, p->d_ub_off); p->d_ub_off = nullptr;
+            PCHK(pool_get(c, (size_t)ns * m + 1, &p->d_ub_off));
+            LAUNCH(c, "smm_row_work", smm_ccs_row_work, wgrid, 256, 0, (int)m, ns, p->ws, (int)p->ncols, (int)b->rows, p->row_offset,
+                   sym ? 1 : 0, a->ptr, a->idx, sseg, d_ubs);
+            PCHK(scan_launch<int64_t>(c, (int64_t)ns * m, d_ubs, p->d_ub_off));
+            {
+                hipError_t e = hipMemcpyAsync(&total_ub, p->d_ub_off + (int64_t)ns * m, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "slab row work: %s", hipGetErrorString(e)); }
+            }
+            pool_free(c, d_ubs);
+            {
+                char *tmp = nullptr;
+                PCHK(pool_get(c, (size_t)std::max<int64_t>(total_ub, 1) * 2, &tmp));
+                p->d_tmp = tmp;
+            }
+            PCHK(pool_get(c, (size_t)a->nnz * ns, &p->d_P));
+            PCHK(pool_get(c, (size_t)ns * m, &p->d_scnt));
+            PCHK(pool_get(c, (size_t)m, &p->d_rowcnt));
+            int *d_unitctr = (int *)((char *)c->d_flags + 208);
+            {
+                hipError_t e = hipMemsetAsync(d_unitctr, 0, sizeof(int), c->stream);
+                if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "memset: %s", hipGetErrorString(e)); }
+            }
+            {
+                const size_t wave_bytes = (size_t)(cc.bm_words + WAVE) * sizeof(unsigned);
+                int cw = 4, best = 0;
+                for (int cand : {4, 2, 1}) {
+                    const int waves = (int)std::min<size_t>(32, ((size_t)160 * 1024 / (cand * wave_bytes)) * cand);
+                    if (waves > best) { best = waves; cw = cand; }
+                }
+                const size_t lds = wave_bytes * cw;
+                const int64_t units = (int64_t)ns * m;
+                if (units >= INT32_MAX) { smm_plan_destroy(p); return fail(SMM_ERR_INVALID, "too many (slab, row) units"); }
+                const int sgrid = (int)std::min<int64_t>((units + cw - 1) / cw, (int64_t)c->n_cu * 8 * (4 / cw));
+                auto kern = sym ? smm_symbolic_ccs<true, SMM_CCS_UNROLL> : smm_symbolic_ccs<false, SMM_CCS_UNROLL>;
+                if (lds > 64 * 1024) {
+                    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e)); }
+                }
+                LAUNCH(c, "smm_symbolic", kern, sgrid, cw * 64, lds, (int)m, ns, (const int *)nullptr, (const int *)nullptr, p->row_offset, cc.ws,
+                       cc.bm_words, (int)b->rows, (int64_t)a->nnz, cc.guard_chunk, a->ptr, a->idx, (const int *)cc.cptr,
+                       (const unsigned short *)cc.stream, (const int64_t *)p->d_ub_off, (unsigned short *)p->d_tmp, p->d_P, p->d_scnt, d_unitctr);
+            }
+            LAUNCH(c, "smm_slab_rowcnt", smm_slab_rowcnt, std::min<int64_t>((m + 255) / 256, 4096), 256, 0, (int)m, ns, (const int *)p->d_scnt,
+                   p->d_rowcnt);
+            PCHK(scan_launch<int>(c, m, p->d_rowcnt, p->d_cptr));
+            {
+                hipError_t e = hipMemcpyAsync(&p->nnz, p->d_cptr + m, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                if (e == hipSuccess) e = hipGetLastError();
+                if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "symbolic phase (slabs): %s", hipGetErrorString(e)); }
+            }
+            if (p->nnz > 0) {
+                // every non-empty row goes to the tile kernel (the hash kernels read one list per row)
+                PCHK(pool_get(c, (size_t)3 * m, &p->d_lists));
+                int *d_counts = (int *)((char *)c->d_flags + 192);
+                hipError_t e = hipMemsetAsync(d_counts, 0, 3 * sizeof(int), c->stream);
+                LAUNCH(c, "smm_bin_rows", smm_bin_rows<int>, std::min<int64_t>((m + 1023) / 1024, 2048), 1024, 0, (int)m, 0, 0,
+                       (const int *)p->d_rowcnt, p->d_lists, d_counts);
+                if (e == hipSuccess) e = hipMemcpyAsync(p->n_bin, d_counts, 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "row binning: %s", hipGetErrorString(e)); }
+            }
+            if (p->n_bin[2] > 0) {
+                if (flags & SMM_EXACT) {
+                    PCHK(ensure_seg(c, b, p->g, &p->seg));
+                    PCHK(ensure_loc(c, b, p->g, &p->loc));
+                } else {
+                    PCHK(ensure_pack(c, b, p->g, &p->pack));
+                }
+                PCHK(pool_get(c, (size_t)a->nnz, &p->d_dst0));
+                PCHK(pool_get(c, (size_t)a->nnz * p->g.nct, &p->d_runs2));
+                const int nd = p->n_bin[2];
+                LAUNCH(c, "smm_runs", smm_runs_slab, std::min<int64_t>((nd + 3) / 4, 65536), 256, 0, nd, (int)m, ns, tps, p->g.nct, p->g.wc,
+                       (int64_t)a->nnz, (const int *)(p->d_lists + 2 * m), a->ptr, (const int64_t *)p->d_ub_off, (const int *)p->d_scnt,
+                       (const unsigned *)p->d_P, (const unsigned short *)p->d_tmp, p->d_dst0, p->d_runs2);
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "smm_runs_slab: %s", hipGetErrorString(e)); }
+            }
+            if (nnz_out) *nnz_out = p->nnz;
+            *plan = p;
+            return SMM_OK;
+        }
+    }
     p->list16 = c->narrow_idx && p->ncols < 65535 && b->cols < 65535;
     if (p->list16) PCHK(ensure_idx16(c, b));
     {
@@ -1462,9 +1590,6 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         }
         const size_t lds = wave_bytes * cw;
         const int sgrid = (int)std::min<int64_t>((nbm + cw - 1) / cw, (int64_t)c->n_cu * 8 * (4 / cw));
-#ifndef SMM_CCS_UNROLL
-#define SMM_CCS_UNROLL 4
-#endif
         auto kern = sym ? smm_symbolic_ccs<true, SMM_CCS_UNROLL> : smm_symbolic_ccs<false, SMM_CCS_UNROLL>;
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1599,6 +1724,7 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
         A.rowsB = (int)p->b->rows;
         A.c_ptr = p->d_cptr; A.c_idx = d_c_indices; A.c_val = d_c_data;
         A.ub_off = p->d_ub_off; A.tmp_idx = p->d_tmp; A.list16 = p->list16 ? 1 : 0; A.runs = p->d_runs; A.tail = p->d_tail;
+        A.runs2 = p->d_runs2; A.n_slabs = p->n_slabs; A.tps = p->tps; A.ws = p->ws; A.mtot = (int)m; A.nnzA = p->a->nnz;
         if (p->use_slab) {
             // values in column order into a dense scratch (one row per row of the bin), then the emission
             double *scratch = nullptr;

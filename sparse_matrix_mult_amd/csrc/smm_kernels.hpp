@@ -1056,6 +1056,135 @@ __global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc, const in
 }
 
 // ---------------------------------------------------------------------------------------
+// Column slabs (round 3, operands with more than CCS_MAX_WS columns).  smm_symbolic_ccs ran once per (slab, row):
+// slab s of row i has its OWN ordered list L_s (slab-local 16-bit columns) and its own P_s[e].  Step e of the row
+// appended, slab after slab, the columns L_s[P_s[e] .. P_s[e+1]) -- so in the row of C the sub-run of (step e,
+// tile t of slab s) starts at
+//     dst = D[e] + sum_{s' < s} c_{s'}[e] + (src - P_s[e]),   D[e] = sum_{e' < e} sum_s c_s[e'],  c_s[e] = P_s[e+1] - P_s[e]
+// where src = first position of L_s in [P_s[e], P_s[e+1]) whose column lies in tile t.  This kernel is smm_runs for
+// that layout: runs2[t * nnzA + e] = { src | len << 16, dst } (src < 2^16: a slab list is at most CCS_MAX_WS long;
+// len <= tile width < 2^15), the table the numeric epilogue walks -- every step is a sub-run step here (no tail:
+// positions in a slab's list are not positions in the result).  One wave per row.
+__global__ __launch_bounds__(256) void smm_slab_rowcnt(int m, int n_slabs, const int *__restrict__ scnt, int *__restrict__ rowcnt)
+{
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < m; row += gridDim.x * blockDim.x) {
+        int t = 0;
+        for (int s = 0; s < n_slabs; ++s) t += scnt[(size_t)s * m + row];
+        rowcnt[row] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void smm_runs_slab(int nrows, int m, int n_slabs, int tps, int nct, int wc, int64_t nnzA,
+                                                     const int *__restrict__ rowlist, const int *__restrict__ a_ptr,
+                                                     const int64_t *__restrict__ list_off, const int *__restrict__ scnt,
+                                                     const unsigned *__restrict__ P, const unsigned short *__restrict__ tmp,
+                                                     unsigned *__restrict__ dst0, uint2 *__restrict__ runs2)
+{
+    __shared__ int win_all[4][RUNS_WIN];
+    constexpr int NV = RUNS_WIN / WAVE;
+    const int lane = lane_id();
+    const int wpb = blockDim.x / WAVE;
+    int *win = win_all[threadIdx.x >> 6];
+    for (int ri = blockIdx.x * wpb + (threadIdx.x >> 6); ri < nrows; ri += gridDim.x * wpb) {
+        const int row = rowlist ? rowlist[ri] : ri;
+        const int a0 = a_ptr[row], a1 = a_ptr[row + 1];
+        auto cnt_of = [&](int s, int e) -> unsigned {         // c_s[e] for a valid entry e of this row
+            const unsigned *Ps = P + (size_t)s * nnzA;
+            const unsigned q1 = e + 1 < a1 ? Ps[e + 1] : (unsigned)scnt[(size_t)s * m + row];
+            return q1 - Ps[e];
+        };
+        // A. D[e]: where step e starts in the row of C
+        unsigned carry = 0;
+        for (int eb = a0; eb < a1; eb += WAVE) {
+            const int e = eb + lane;
+            int C = 0;
+            if (e < a1)
+                for (int s = 0; s < n_slabs; ++s) C += (int)cnt_of(s, e);
+            const int incl = wave_scan_incl(C);
+            if (e < a1) dst0[e] = carry + (unsigned)(incl - C);
+            carry += (unsigned)rl(incl, WAVE - 1);
+        }
+        // B. per slab: tile boundaries inside every step's segment of the slab's list (the list is streamed once
+        //    through LDS windows, as in smm_runs), then the table entries of the slab's tiles
+        for (int s = 0; s < n_slabs; ++s) {
+            const int t0 = s * tps;
+            const int tsl = (nct - t0) < tps ? (nct - t0) : tps;             // tiles of this slab
+            const unsigned short *__restrict__ list = tmp + list_off[(size_t)s * m + row];
+            const unsigned total = (unsigned)scnt[(size_t)s * m + row];
+            const unsigned *__restrict__ Ps = P + (size_t)s * nnzA;
+            int v[NV];
+            auto fetch = [&](unsigned wb) {
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const unsigned i = wb + u * WAVE + lane;
+                    v[u] = (int)list[i < total ? i : (total ? total - 1 : 0)];
+                }
+            };
+            unsigned cur = 0xffffffffu;
+            if (total) fetch(0);
+            for (int eb = a0; eb < a1; eb += WAVE) {
+                const int e = eb + lane;
+                const bool valid = e < a1;
+                const unsigned p0 = valid ? Ps[e] : total;
+                const unsigned p1 = (valid && e + 1 < a1) ? Ps[e + 1] : total;
+                uint2 *r = runs2 + (size_t)t0 * nnzA + (valid ? e : a1 - 1);     // r[tt * nnzA].x = start of tile tt's part
+                int tcur = 1;
+                if (valid) {
+                    r[0].x = p0;
+                    if (p0 == p1) { for (; tcur < tsl; ++tcur) r[(size_t)tcur * nnzA].x = p0; }
+                } else {
+                    tcur = tsl;
+                }
+                const unsigned reg_lo = rl(p0, 0), reg_hi = rl(p1, WAVE - 1);
+                for (unsigned wb = reg_lo - reg_lo % RUNS_WIN; wb < reg_hi; wb += RUNS_WIN) {
+                    const unsigned we = wb + RUNS_WIN < total ? wb + RUNS_WIN : total;
+                    if (wb != cur) {
+                        wave_sync();
+#pragma unroll
+                        for (int u = 0; u < NV; ++u) win[u * WAVE + lane] = v[u];
+                        cur = wb;
+                        if (we < total) fetch(we);
+                        wave_sync();
+                    }
+                    unsigned lo = p0 > wb ? p0 : wb;
+                    const unsigned hiw = p1 < we ? p1 : we;
+                    if (lo < hiw) {
+                        while (tcur < tsl) {
+                            const int bound = tcur * wc;                 // slab-local column where tile tcur of the slab starts
+                            unsigned l = lo, h = hiw;
+                            while (l < h) {
+                                const unsigned mid = l + ((h - l) >> 1);
+                                if (win[mid - wb] < bound) l = mid + 1; else h = mid;
+                            }
+                            if (l < hiw) { r[(size_t)tcur * nnzA].x = l; lo = l; ++tcur; }
+                            else if (p1 <= we) { r[(size_t)tcur * nnzA].x = p1; lo = hiw; ++tcur; }
+                            else break;
+                        }
+                    }
+                }
+            }
+            // the table entries (the starts written above are read back by the lane that wrote them)
+            __threadfence_block();
+            for (int eb = a0; eb < a1; eb += WAVE) {
+                const int e = eb + lane;
+                if (e >= a1) continue;
+                const unsigned p0 = Ps[e];
+                const unsigned p1 = e + 1 < a1 ? Ps[e + 1] : total;
+                unsigned base = dst0[e];
+                for (int sp = 0; sp < s; ++sp) base += cnt_of(sp, e);
+                uint2 *r = runs2 + (size_t)t0 * nnzA + e;
+                unsigned st = r[0].x;
+                for (int tt = 0; tt < tsl; ++tt) {
+                    const unsigned en = tt + 1 < tsl ? r[(size_t)(tt + 1) * nnzA].x : p1;
+                    r[(size_t)tt * nnzA] = make_uint2(st | ((en - st) << 16), base + (st - p0));
+                    st = en;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Numeric phase.  Workgroup = one (row, coarse tile) unit, tile-major so that concurrent
 // units read the same column slab of B; NW waves; LDS = wc f64 accumulators.
 //   OUT_DENSE : accumulators start at +0.0 (calloc, sparse_sparse_dense.cpp:97); the tile is
@@ -1094,6 +1223,8 @@ struct NumericArgs {
     const unsigned *runs;           // [nnzA][nct+1] sub-run table (smm_runs), steps before the tail
     const int2 *tail;               // [rows] {first step of the tail, its list position}
     const int *rowlist;             // rows handled by this launch (NULL = all m rows)
+    // column slabs (smm_runs_slab): slab-local lists, ub_off indexed [slab * mtot + row]
+    const uint2 *runs2; int n_slabs, tps, ws, mtot; int64_t nnzA;
     unsigned long long *stamps;     // diagnostic builds (-DSMM_STAMPS) only: 4 phase totals
     // dense output
     double *c_dense; int64_t ldc;
@@ -1354,10 +1485,11 @@ constexpr int EPI_UNROLL = SMM_EPI_UNROLL;
 // the first-touch emission.
 // L16: the ordered lists are uint16 (a template parameter, not a run-time switch: a branch inside the epilogue's
 // "all loads first" loop made every load wait for the one before it -- 30 -> 37 ms).
-template <int OUT, bool SYM, int NW, bool EXACT, bool SCR = false, bool L16 = false>
+template <int OUT, bool SYM, int NW, bool EXACT, bool SCR = false, bool L16 = false, bool SLAB = false>
 __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
 {
     static_assert(!SCR || OUT == OUT_SPARSE, "the scratch source feeds the CSR emission only");
+    static_assert(!SLAB || (OUT == OUT_SPARSE && L16 && !SCR), "slab-local lists: CSR output, 16-bit lists");
     extern __shared__ double acc[];
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1417,6 +1549,44 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
     if (OUT == OUT_DENSE) {
         double *__restrict__ dst = A.c_dense + (int64_t)row * A.ldc + lo_c;
         for (int x = threadIdx.x; x < w; x += NT) st_stream(&dst[x], acc[x]);
+    } else if constexpr (SLAB) {
+        // Epilogue over slab-local lists (smm_runs_slab): step e's columns of this tile are the entries
+        // [src, src + len) of the slab's list and go to [dst, dst + len) of the row of C.  Same chunking as below.
+        const int sl_ = tc / A.tps;
+        const unsigned short *__restrict__ list = (const unsigned short *)A.tmp_idx + A.ub_off[(size_t)sl_ * A.mtot + row];
+        const uint2 *__restrict__ rt = A.runs2 + (size_t)tc * A.nnzA;
+        const int cshift = sl_ * A.ws;                       // slab-local column -> global column
+        const int ashift = cshift - lo_c;                    // slab-local column -> accumulator of this tile
+        int *__restrict__ oi = A.c_idx + rs;
+        double *__restrict__ ov = A.c_val + rs;
+        for (int rb = a0; rb < a1; rb += NW * WAVE) {
+            const int e = rb + wave + NW * lane;
+            const bool ev = e < a1;
+            const uint2 d = rt[ev ? e : a1 - 1];
+            const unsigned src0 = d.x & 0xffffu, len = ev ? d.x >> 16 : 0u, dst0 = d.y;
+            const int nch = (int)((len + WAVE - 1) >> 6);
+            const int incl = wave_scan_incl(nch);
+            const int total = rl(incl, WAVE - 1);
+            for (int t0 = 0; t0 < total; t0 += EPI_UNROLL) {
+                int c[EPI_UNROLL];
+                unsigned dl[EPI_UNROLL];
+#pragma unroll
+                for (int u = 0; u < EPI_UNROLL; ++u) {          // all chunk loads of the round first
+                    const int t = t0 + u;
+                    int i = (int)__popcll(__ballot(incl <= t));
+                    i = i < WAVE ? i : WAVE - 1;
+                    const int first = rl(incl, i) - rl(nch, i);
+                    const unsigned off = ((unsigned)(t - first) << 6) + (unsigned)lane;
+                    const bool p = t < total && off < rl(len, i);
+                    dl[u] = rl(dst0, i) + off;
+                    const unsigned short *ip = p ? list + rl(src0, i) + off : (const unsigned short *)A.dummy_idx;
+                    c[u] = (int)ld_stream(ip);
+                }
+#pragma unroll
+                for (int u = 0; u < EPI_UNROLL; ++u)        // idle lanes read the dummy word: 0xffff, no slab-local column (ws <= 63 456)
+                    if (c[u] != 0xffff) { st_stream(&oi[dl[u]], c[u] + cshift); st_stream(&ov[dl[u]], acc[c[u] + ashift]); }
+            }
+        }
     } else {
         // Epilogue.  Step e of the row put its new columns of this tile into the contiguous slots
         // [runs[e][tc], runs[e][tc+1]).  The sub-runs are cut into 64-lane chunks; wave w takes the

@@ -81,6 +81,10 @@ class Context:
         """uint16 column stream / lists in the symbolic phase for operands with < 65535 columns (default on)."""
         check(self.lib, self.lib.smm_ctx_tune_narrow(self.handle, 1 if enable else 0))
 
+    def tune_symbolic(self, max_slab_cols=0):
+        """Widest column slab of the symbolic walk (0 = default 63456); a wider B is walked slab by slab."""
+        check(self.lib, self.lib.smm_ctx_tune_symbolic(self.handle, int(max_slab_cols)))
+
     def exact_selftest(self, inject_fault=False):
         """Run the SMM_EXACT guard now (every context runs it by itself before its first exact product):
         raises SmmError (code SMM_ERR_UNSUPPORTED) where the device does not add same-address lanes of one
