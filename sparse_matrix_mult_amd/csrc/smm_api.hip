@@ -66,6 +66,7 @@ struct smm_ctx {
     bool timing = false;
     int sym_wide = 1;        // symbolic phase on 16-bit columns: chunks of 128 entries (env SMM_SYM_WIDE=0: 64)
     int sym_ccs = 1;         // symbolic phase over the chunk-padded column stream (smm_symbolic_ccs; env SMM_SYM_CCS=0: smm_symbolic)
+    int piece_walk = 1;      // default mode: one piece of B per wave iteration where every piece has <= 256 entries (env SMM_PIECE_WALK=0: chunk walk)
     int sym_max_ws = 0;      // widest column slab of that walk (0 = CCS_MAX_WS); B with more columns is walked slab by slab
                              // (smm_ctx_tune_symbolic; tests set it small to reach the slab path with small matrices)
     int s2_group = 5;        // triple stage 2: k-groups whose blocks follow each other on one XCD and share a tile of T
@@ -191,6 +192,7 @@ extern "C" int smm_ctx_create(int device, void *hip_stream, smm_ctx **out)
     if (const char *e = getenv("SMM_S2_GROUP")) c->s2_group = std::max(1, atoi(e));
     if (const char *e = getenv("SMM_SYM_WIDE")) c->sym_wide = atoi(e) != 0;
     if (const char *e = getenv("SMM_SYM_CCS")) c->sym_ccs = atoi(e) != 0;
+    if (const char *e = getenv("SMM_PIECE_WALK")) c->piece_walk = atoi(e) != 0;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hip_stream == SMM_STREAM_DEFAULT) { c->stream = nullptr; c->own_stream = false; }   // the device's null stream
     else if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
@@ -564,7 +566,7 @@ struct smm_csr {
     struct SlabCache { int ws, n_slabs; int *soff; short *scol; double *sval; };   // slab-major copy (smm_slab.hpp)
     std::vector<SegCache> segs;
     std::vector<LocCache> locs;
-    struct PackCache { int wc, nct; int2 *desc; double *pay; };   // packed tile-major payload (smm_pack_*)
+    struct PackCache { int wc, nct; int2 *desc; double *pay; int maxlen; };   // packed tile-major payload (smm_pack_*); longest piece
     std::vector<SlabCache> slabs;
     std::vector<PackCache> packs;
     // chunk-padded 16-bit column stream per column slab (smm_ccs_*): the symbolic phase's gather stream
@@ -889,7 +891,7 @@ static int launch_numeric_t(smm_ctx *c, NumericArgs &args)
     }
     // accumulator tile (+ the exact walk's per-wave scratch behind it)
     // accumulators (+ the exact walk's per-wave scratch and the workgroup's 64-slot sink behind them)
-    const size_t lds = (size_t)((args.wc + 1) & ~1) * sizeof(double) + (EXACT ? (size_t)NW * sizeof(ExactScratch) + 64 * sizeof(double) : 0);
+    const size_t lds = (size_t)(((args.wc + 1) & ~1) + 2) * sizeof(double) + (EXACT ? (size_t)NW * sizeof(ExactScratch) + 64 * sizeof(double) : 0);
     auto kern = smm_numeric<OUT, SYM, NW, EXACT, SCR, L16, SLAB>;
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -961,7 +963,7 @@ struct smm_plan {
     uint2 *d_runs2 = nullptr;      // nct x nnz(A)
     const int *seg = nullptr;      // B's tile index and tile-local columns for geometry g (owned by b)
     const short *loc = nullptr;
-    smm_csr::PackCache pack{0, 0, nullptr, nullptr};   // default mode: packed payload of B for geometry g
+    smm_csr::PackCache pack{0, 0, nullptr, nullptr, 0};   // default mode: packed payload of B for geometry g
     bool use_slab = false;         // dense-bin rows: smm_dense_slab -> scratch -> emission, instead of the tile kernel
     SlabGeom sg{};
     smm_csr::SlabCache slab{0, 0, nullptr, nullptr, nullptr};
@@ -1036,19 +1038,24 @@ static int ensure_pack(smm_ctx *c, smm_csr *b, const Geom &g, smm_csr::PackCache
     CHK(pool_get(c, (size_t)std::max<int64_t>(cells, 1), &units));
     int rc = pool_get(c, (size_t)cells + 1, &off64);
     if (rc != SMM_OK) { pool_free(c, units); return rc; }
-    if (cells > 0) LAUNCH(c, "smm_pack_count", smm_pack_count, (cells + 255) / 256, 256, 0, (int)b->rows, g.nct, seg, units);
+    int *d_maxlen = (int *)((char *)c->d_flags + 244);
+    (void)hipMemsetAsync(d_maxlen, 0, sizeof(int), c->stream);
+    if (cells > 0) LAUNCH(c, "smm_pack_count", smm_pack_count, (cells + 255) / 256, 256, 0, (int)b->rows, g.nct, seg, units, d_maxlen);
     rc = scan_launch<int>(c, cells, units, off64);
     int64_t total = 0;
+    int maxlen = 0;
     if (rc == SMM_OK) {
         hipError_t e = hipMemcpyAsync(&total, off64 + cells, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&maxlen, d_maxlen, sizeof(int), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) rc = fail(SMM_ERR_HIP, "pack build: %s", hipGetErrorString(e));
     }
     if (rc == SMM_OK && total >= INT32_MAX) rc = fail(SMM_ERR_INVALID, "operand too large for the packed payload");
-    smm_csr::PackCache e{g.wc, g.nct, nullptr, nullptr};
+    smm_csr::PackCache e{g.wc, g.nct, nullptr, nullptr, maxlen};
+    // (+ 4 units of slack: the piece walk's last lane reads up to three 8-byte units past a very short last piece)
     if (rc == SMM_OK &&
         (hipMalloc((void **)&e.desc, (size_t)std::max<int64_t>(cells, 1) * sizeof(int2)) != hipSuccess ||
-         hipMalloc((void **)&e.pay, (size_t)std::max<int64_t>(total, 1) * sizeof(double)) != hipSuccess)) {
+         hipMalloc((void **)&e.pay, (size_t)(std::max<int64_t>(total, 1) + 4) * sizeof(double)) != hipSuccess)) {
         (void)hipFree(e.desc); (void)hipFree(e.pay);
         rc = fail(SMM_ERR_ALLOC, "hipMalloc of the packed payload failed");
     }
@@ -1063,7 +1070,7 @@ static int ensure_pack(smm_ctx *c, smm_csr *b, const Geom &g, smm_csr::PackCache
     pool_free(c, units); pool_free(c, off64);
     if (rc != SMM_OK) return rc;
     b->packs.push_back(e);
-    b->derived_bytes += std::max<int64_t>(cells, 1) * (int64_t)sizeof(int2) + std::max<int64_t>(total, 1) * (int64_t)sizeof(double);
+    b->derived_bytes += std::max<int64_t>(cells, 1) * (int64_t)sizeof(int2) + (std::max<int64_t>(total, 1) + 4) * (int64_t)sizeof(double);
     *out = e;
     return SMM_OK;
 }
@@ -1721,6 +1728,7 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
         A.b_idx = p->b->idx; A.b_val = p->b->val; A.seg = p->seg; A.b_loc = p->loc;
         A.kmax = (int)std::max<int64_t>(p->b->nnz - 1, 0);
         A.tdesc = p->pack.desc; A.tpay = p->pack.pay;
+        A.piece_epl = !c->piece_walk || !p->pack.pay ? 0 : (p->pack.maxlen <= 128 ? 2 : (p->pack.maxlen <= 256 ? 4 : 0));
         A.rowsB = (int)p->b->rows;
         A.c_ptr = p->d_cptr; A.c_idx = d_c_indices; A.c_val = d_c_data;
         A.ub_off = p->d_ub_off; A.tmp_idx = p->d_tmp; A.list16 = p->list16 ? 1 : 0; A.runs = p->d_runs; A.tail = p->d_tail;
@@ -1828,7 +1836,7 @@ static int dense_into(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t row
     if (!(b->vflags & CSR_UNSORTED)) {
         Geom g = make_geom(c, n, b, (flags & SMM_EXACT) != 0);
         const int *seg = nullptr; const short *loc = nullptr;
-        smm_csr::PackCache pack{0, 0, nullptr, nullptr};
+        smm_csr::PackCache pack{0, 0, nullptr, nullptr, 0};
         if (flags & SMM_EXACT) {
             CHK(ensure_seg(c, b, g, &seg));
             CHK(ensure_loc(c, b, g, &loc));
@@ -1842,6 +1850,7 @@ static int dense_into(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t row
         A.b_idx = b->idx; A.b_val = b->val; A.seg = seg; A.b_loc = loc;
         A.kmax = (int)std::max<int64_t>(b->nnz - 1, 0);
         A.tdesc = pack.desc; A.tpay = pack.pay;
+        A.piece_epl = !c->piece_walk || !pack.pay ? 0 : (pack.maxlen <= 128 ? 2 : (pack.maxlen <= 256 ? 4 : 0));
         A.rowsB = (int)b->rows;
         A.c_dense = d_c; A.ldc = ldc;
         CHK(launch_numeric<OUT_DENSE>(c, A, sym, g.nw, (flags & SMM_EXACT) != 0));

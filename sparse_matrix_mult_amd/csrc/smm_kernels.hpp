@@ -301,14 +301,20 @@ __global__ __launch_bounds__(256) void smm_loc16(int nnz, int wc, const int *__r
 // bytes) -- and the blocks of a tile follow each other in row order.  desc[t*rows + j] = {first 8-byte unit,
 // entries}.  Against the separate loc16[] / val[] arrays in CSR order a piece touches two partial cache lines
 // instead of four (-12 GB of fabric reads per 50k x 50k product), and its bounds are one 8-byte load.
-__global__ __launch_bounds__(256) void smm_pack_count(int rows, int nct, const int *__restrict__ seg, int *__restrict__ units)
+__global__ __launch_bounds__(256) void smm_pack_count(int rows, int nct, const int *__restrict__ seg, int *__restrict__ units,
+                                                      int *__restrict__ maxlen)
 {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (int64_t)rows * nct) return;
-    const int t = (int)(gid / rows), j = (int)(gid % rows);
-    const int *sp = seg + (size_t)j * (nct + 1) + t;
-    const int len = sp[1] - sp[0];
-    units[gid] = (len + ((len + 3) >> 2) + 1) & ~1;        // 16-byte pieces: the wide-chunk walk loads value pairs
+    int len = 0;
+    if (gid < (int64_t)rows * nct) {
+        const int t = (int)(gid / rows), j = (int)(gid % rows);
+        const int *sp = seg + (size_t)j * (nct + 1) + t;
+        len = sp[1] - sp[0];
+        units[gid] = (len + ((len + 3) >> 2) + 1) & ~1;    // 16-byte pieces: the wide-chunk walk loads value pairs
+    }
+    int mx = len;                                          // the longest piece decides which accumulate walk can run
+    for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
+    if (lane_id() == 0 && mx > 0) atomicMax(maxlen, mx);
 }
 __global__ __launch_bounds__(256) void smm_pack_desc(int rows, int nct, const int *__restrict__ seg, const int64_t *__restrict__ off,
                                                      int2 *__restrict__ desc)
@@ -334,7 +340,10 @@ __global__ __launch_bounds__(256) void smm_pack_fill(int rows, int nct, int wc, 
             const int2 d = desc[(size_t)t * rows + j];
             const int pos = k - sp[t];
             pay[d.x + pos] = val[k];
-            ((short *)(pay + d.x + d.y))[pos] = (short)(c - t * wc);
+            short *cols = (short *)(pay + d.x + d.y);
+            cols[pos] = (short)(c - t * wc);
+            if (pos == d.y - 1)                            // the rest of the last 8-byte unit of columns: the sink accumulator
+                for (int q = d.y; q < ((d.y + 3) & ~3); ++q) cols[q] = (short)((wc + 1) & ~1);
         }
     }
 }
@@ -966,7 +975,10 @@ __global__ __launch_bounds__(256) void smm_symbolic_ccs(int m, int n_slabs, cons
 // load and two partial stores per sub-run.  Those steps get no sub-run table: the numeric epilogue walks the
 // list positions [P[e0], end) contiguously, 64 at a time, and every tile's unit keeps the columns that are
 // its own (positions in the list ARE positions in the result).  tail[row] = {e0, P[e0]}.
-constexpr int TAIL_MIN = 64;
+#ifndef SMM_TAIL_MIN
+#define SMM_TAIL_MIN 64
+#endif
+constexpr int TAIL_MIN = SMM_TAIL_MIN;
 constexpr int RUNS_WIN = 2048;
 template <typename LT>
 __global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc, const int *__restrict__ rowlist,
@@ -1212,6 +1224,7 @@ struct NumericArgs {
     const int *b_idx; const double *b_val;
     const short *b_loc;             // tile-local columns (smm_loc16): the exact walk
     const int2 *tdesc; const double *tpay; int rowsB;   // packed tile-major payload (smm_pack_*): the shared-tile walk
+    int piece_epl;                  // 2 / 4: every piece of the payload has <= 128 / 256 entries -> smm_accumulate_pieces; 0: chunk walk
     const int *seg;                 // [rowsB][n_ft+1]
     int kmax;                       // last valid position of b_loc / b_val (exact walk: lanes past a stream's end read it)
     const int *dummy_idx;           // one int  = -1   (read by inactive lanes; its low half is the int16 -1)
@@ -1456,6 +1469,117 @@ __device__ __forceinline__ void smm_accumulate_shared(const NumericArgs &A, doub
     }
 }
 
+// Piece walk (round 3, default mode).  Where every piece of the packed payload has at most 64 * EPL entries (EPL = 2
+// or 4 entries per lane: 128 / 256; the longest piece is known when the payload is built) a wave does not need the
+// chunk list at all: ONE piece per iteration, lane l takes its entries EPL*l .. EPL*l + EPL-1 -- one or two 16-byte
+// loads of values and one 4- or 8-byte load of columns, all three with a scalar base and a constant per-lane offset
+// under an EXEC mask of ceil(n / EPL) lanes -- then EPL multiply-adds into the tile.  No scan, no owner search, no
+// per-lane predicate: the columns behind a piece's last entry are the tile's SINK accumulator (smm_pack_fill pads
+// the column block with it), so whatever a lane multiplies there lands where nobody reads.  Per piece of ~170
+// entries that is ~12 vector and ~12 scalar instructions against ~80 + 40 of the chunk walk; bytes and order of
+// issue of the gather are the same.  U pieces are in flight per wave and round.
+typedef double dpair_t __attribute__((ext_vector_type(2), aligned(8)));
+typedef int ipair_t __attribute__((ext_vector_type(2)));
+#ifndef SMM_PIECE_U
+#define SMM_PIECE_U 4
+#endif
+__device__ __forceinline__ void wait_vm_n(int n) {
+#define SMM_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    switch (n) {
+        SMM_W(0) SMM_W(1) SMM_W(2) SMM_W(3) SMM_W(4) SMM_W(5) SMM_W(6) SMM_W(7)
+        SMM_W(8) SMM_W(9) SMM_W(10) SMM_W(11) SMM_W(12) SMM_W(13) SMM_W(14) SMM_W(15)
+        SMM_W(16) SMM_W(17) SMM_W(18) SMM_W(19) SMM_W(20) SMM_W(21) SMM_W(22) SMM_W(23)
+        SMM_W(24) SMM_W(25) SMM_W(26) SMM_W(27) SMM_W(28) SMM_W(29) SMM_W(30) SMM_W(31)
+    }
+#undef SMM_W
+}
+template <bool SYM, int NW, int EPL>
+__device__ __forceinline__ void smm_accumulate_pieces(const NumericArgs &A, double *__restrict__ acc, const int thresh,
+                                                      const int a0, const int a1, const int tc, const int wave)
+{
+    static_assert(EPL == 2 || EPL == 4, "entries per lane");
+    constexpr int U = SMM_PIECE_U;
+    constexpr int LPP = EPL == 4 ? 3 : 2;                   // loads per piece
+    const int lane = lane_id();
+    const int2 *__restrict__ desc = A.tdesc + (size_t)tc * A.rowsB;
+    const double *__restrict__ pay = A.tpay;
+    const unsigned acc_a = lds_addr(acc);
+    const int sink = (A.wc + 1) & ~1;
+    const int voff = lane * (EPL * 8), coff = lane * (EPL * 2);
+    for (int rb = a0; rb < a1; rb += NW * WAVE) {
+        const int e = rb + wave + NW * lane;
+        const bool ev = e < a1;
+        const int ec = ev ? e : a1 - 1;
+        const int r = A.a_idx[ec];
+        const double av = A.a_val[ec];
+        const int2 d = desc[r];                             // {first 8-byte unit of the piece, entries}
+        const int s_l = d.x, n_l = ev ? d.y : 0;
+        int cnt = (a1 - rb - wave + NW - 1) / NW;           // this wave's entries of the round (wave-uniform)
+        cnt = cnt < 0 ? 0 : (cnt > WAVE ? WAVE : cnt);
+        for (int i0 = 0; i0 < cnt; i0 += U) {
+            dpair_t v0[U], v1[U];
+            ipair_t cc[U];
+            unsigned long long mk[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                   // every load of the round first
+                const int i = i0 + u < cnt ? i0 + u : cnt - 1;
+                const int sp = rl(s_l, i);
+                const int n = i0 + u < cnt ? rl(n_l, i) : 0;
+                const int nl = (n + EPL - 1) / EPL;         // lanes with entries
+                mk[u] = nl >= WAVE ? ~0ull : (1ull << nl) - 1ull;
+                // (an empty piece or a dead slot still loads with lane 0 -- from inside the payload, never added -- so that
+                // every slot counts exactly LPP loads and the counted waits below hold)
+                const unsigned long long lm = mk[u] | 1ull;
+                const double *vb = pay + sp;
+                const void *cb = (const void *)(pay + sp + n);
+                if constexpr (EPL == 4)
+                    asm volatile("s_mov_b64 exec, %7\n\t"
+                                 "global_load_dwordx4 %0, %3, %5\n\t"
+                                 "global_load_dwordx4 %1, %3, %5 offset:16\n\t"
+                                 "global_load_dwordx2 %2, %4, %6\n\t"
+                                 "s_mov_b64 exec, -1"
+                                 : "=v"(v0[u]), "=v"(v1[u]), "=v"(cc[u])
+                                 : "v"(voff), "v"(coff), "s"(vb), "s"(cb), "s"(lm) : "memory");
+                else
+                    asm volatile("s_mov_b64 exec, %6\n\t"
+                                 "global_load_dwordx4 %0, %2, %4\n\t"
+                                 "global_load_dword %1, %3, %5\n\t"
+                                 "s_mov_b64 exec, -1"
+                                 : "=v"(v0[u]), "=v"(cc[u].x)
+                                 : "v"(voff), "v"(coff), "s"(vb), "s"(cb), "s"(lm) : "memory");
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                wait_vm_n(LPP * (U - 1 - u));
+                if constexpr (EPL == 4) asm volatile("" : "+v"(v0[u]), "+v"(v1[u]), "+v"(cc[u]));
+                else asm volatile("" : "+v"(v0[u]), "+v"(cc[u].x));
+                const int i = i0 + u < cnt ? i0 + u : cnt - 1;
+                const double a = rl(av, i);
+                int c0 = (int)(short)(cc[u].x & 0xffff), c1 = cc[u].x >> 16;
+                if (SYM) { c0 = c0 >= thresh ? c0 : sink; c1 = c1 >= thresh ? c1 : sink; }
+                const unsigned d0 = acc_a + 8u * (unsigned)c0, d1 = acc_a + 8u * (unsigned)c1;
+                const double p0 = a * v0[u].x, p1 = a * v0[u].y;
+                if constexpr (EPL == 4) {
+                    int c2 = (int)(short)(cc[u].y & 0xffff), c3 = cc[u].y >> 16;
+                    if (SYM) { c2 = c2 >= thresh ? c2 : sink; c3 = c3 >= thresh ? c3 : sink; }
+                    const unsigned d2 = acc_a + 8u * (unsigned)c2, d3 = acc_a + 8u * (unsigned)c3;
+                    const double p2 = a * v1[u].x, p3 = a * v1[u].y;
+                    asm volatile("s_mov_b64 exec, %8\n\t"
+                                 "ds_add_f64 %0, %1\n\tds_add_f64 %2, %3\n\tds_add_f64 %4, %5\n\tds_add_f64 %6, %7\n\t"
+                                 "s_mov_b64 exec, -1"
+                                 :: "v"(d0), "v"(p0), "v"(d1), "v"(p1), "v"(d2), "v"(p2), "v"(d3), "v"(p3), "s"(mk[u]) : "memory");
+                } else {
+                    asm volatile("s_mov_b64 exec, %4\n\t"
+                                 "ds_add_f64 %0, %1\n\tds_add_f64 %2, %3\n\t"
+                                 "s_mov_b64 exec, -1"
+                                 :: "v"(d0), "v"(p0), "v"(d1), "v"(p1), "s"(mk[u]) : "memory");
+                }
+            }
+        }
+    }
+    wait_lgkm0();                                           // the hand-issued ds_add's (the compiler does not count them)
+}
+
 #ifndef SMM_EPI_UNROLL
 #define SMM_EPI_UNROLL 8
 #endif
@@ -1536,10 +1660,12 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
         SMM_LAP(t_init);
         if (!below && a1 > a0) {
             if (EXACT) {
-                ExactScratch *scr = (ExactScratch *)(acc + ((A.wc + 1) & ~1));
+                ExactScratch *scr = (ExactScratch *)(acc + ((A.wc + 1) & ~1) + 2);      // (+ the sink accumulators of the piece walk)
                 smm_accumulate<SYM>(A, acc, scr + wave, (double *)(scr + NW), thresh, a0, a1, tc * NW + wave);
                 wait_lgkm0();                   // its hand-issued ds_add's (the compiler does not count them)
             }
+            else if (A.piece_epl == 4) smm_accumulate_pieces<SYM, NW, 4>(A, acc, thresh, a0, a1, tc, wave);
+            else if (A.piece_epl == 2) smm_accumulate_pieces<SYM, NW, 2>(A, acc, thresh, a0, a1, tc, wave);
             else       smm_accumulate_shared<SYM, NW, (OUT == OUT_DENSE ? CH_UNROLL_DENSE : CH_UNROLL_SPARSE)>(A, acc, lo_c, thresh, a0, a1, tc, wave);
         }
     }
