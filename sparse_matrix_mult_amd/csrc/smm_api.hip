@@ -192,7 +192,7 @@ extern "C" int smm_ctx_create(int device, void *hip_stream, smm_ctx **out)
     if (const char *e = getenv("SMM_S2_GROUP")) c->s2_group = std::max(1, atoi(e));
     if (const char *e = getenv("SMM_SYM_WIDE")) c->sym_wide = atoi(e) != 0;
     if (const char *e = getenv("SMM_SYM_CCS")) c->sym_ccs = atoi(e) != 0;
-    if (const char *e = getenv("SMM_PIECE_WALK")) c->piece_walk = atoi(e) != 0;
+    if (const char *e = getenv("SMM_PIECE_WALK")) c->piece_walk = atoi(e);
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hip_stream == SMM_STREAM_DEFAULT) { c->stream = nullptr; c->own_stream = false; }   // the device's null stream
     else if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
@@ -1850,7 +1850,9 @@ static int dense_into(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t row
         A.b_idx = b->idx; A.b_val = b->val; A.seg = seg; A.b_loc = loc;
         A.kmax = (int)std::max<int64_t>(b->nnz - 1, 0);
         A.tdesc = pack.desc; A.tpay = pack.pay;
-        A.piece_epl = !c->piece_walk || !pack.pay ? 0 : (pack.maxlen <= 128 ? 2 : (pack.maxlen <= 256 ? 4 : 0));
+        // (dense output keeps the chunk walk: the piece walk measured 0.9 ms slower at configs[2] and 1.2-2 ms at stage 1 of
+        // configs[3] with 1-3 pieces in flight -- profiles/r3_c_piece_walk.txt; env SMM_PIECE_WALK=2 forces it here too)
+        A.piece_epl = c->piece_walk < 2 || !pack.pay ? 0 : (pack.maxlen <= 128 ? 2 : (pack.maxlen <= 256 ? 4 : 0));
         A.rowsB = (int)b->rows;
         A.c_dense = d_c; A.ldc = ldc;
         CHK(launch_numeric<OUT_DENSE>(c, A, sym, g.nw, (flags & SMM_EXACT) != 0));

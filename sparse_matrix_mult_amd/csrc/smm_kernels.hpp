@@ -1480,8 +1480,11 @@ __device__ __forceinline__ void smm_accumulate_shared(const NumericArgs &A, doub
 // issue of the gather are the same.  U pieces are in flight per wave and round.
 typedef double dpair_t __attribute__((ext_vector_type(2), aligned(8)));
 typedef int ipair_t __attribute__((ext_vector_type(2)));
-#ifndef SMM_PIECE_U
-#define SMM_PIECE_U 4
+#ifndef SMM_PIECE_U_SPARSE
+#define SMM_PIECE_U_SPARSE 4
+#endif
+#ifndef SMM_PIECE_U_DENSE
+#define SMM_PIECE_U_DENSE 2
 #endif
 __device__ __forceinline__ void wait_vm_n(int n) {
 #define SMM_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
@@ -1493,12 +1496,11 @@ __device__ __forceinline__ void wait_vm_n(int n) {
     }
 #undef SMM_W
 }
-template <bool SYM, int NW, int EPL>
+template <bool SYM, int NW, int EPL, int U>
 __device__ __forceinline__ void smm_accumulate_pieces(const NumericArgs &A, double *__restrict__ acc, const int thresh,
                                                       const int a0, const int a1, const int tc, const int wave)
 {
     static_assert(EPL == 2 || EPL == 4, "entries per lane");
-    constexpr int U = SMM_PIECE_U;
     constexpr int LPP = EPL == 4 ? 3 : 2;                   // loads per piece
     const int lane = lane_id();
     const int2 *__restrict__ desc = A.tdesc + (size_t)tc * A.rowsB;
@@ -1664,8 +1666,8 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
                 smm_accumulate<SYM>(A, acc, scr + wave, (double *)(scr + NW), thresh, a0, a1, tc * NW + wave);
                 wait_lgkm0();                   // its hand-issued ds_add's (the compiler does not count them)
             }
-            else if (A.piece_epl == 4) smm_accumulate_pieces<SYM, NW, 4>(A, acc, thresh, a0, a1, tc, wave);
-            else if (A.piece_epl == 2) smm_accumulate_pieces<SYM, NW, 2>(A, acc, thresh, a0, a1, tc, wave);
+            else if (A.piece_epl == 4) smm_accumulate_pieces<SYM, NW, 4, (OUT == OUT_DENSE ? SMM_PIECE_U_DENSE : SMM_PIECE_U_SPARSE)>(A, acc, thresh, a0, a1, tc, wave);
+            else if (A.piece_epl == 2) smm_accumulate_pieces<SYM, NW, 2, (OUT == OUT_DENSE ? SMM_PIECE_U_DENSE : SMM_PIECE_U_SPARSE)>(A, acc, thresh, a0, a1, tc, wave);
             else       smm_accumulate_shared<SYM, NW, (OUT == OUT_DENSE ? CH_UNROLL_DENSE : CH_UNROLL_SPARSE)>(A, acc, lo_c, thresh, a0, a1, tc, wave);
         }
     }
