@@ -301,6 +301,12 @@ __global__ __launch_bounds__(256) void smm_loc16(int nnz, int wc, const int *__r
 // bytes) -- and the blocks of a tile follow each other in row order.  desc[t*rows + j] = {first 8-byte unit,
 // entries}.  Against the separate loc16[] / val[] arrays in CSR order a piece touches two partial cache lines
 // instead of four (-12 GB of fabric reads per 50k x 50k product), and its bounds are one 8-byte load.
+// Pieces of the packed payload start on 128-byte lines (16 units of 8 bytes): a piece of ~1.7 KB then touches 14 lines instead
+// of 14.1 + 1 (round 3, interleaved A/B on one box: configs[1] smm_numeric 25.67 -> 25.43 ms, configs[2] 20.22 -> 19.87,
+// configs[4] share 59.75 -> 58.28; stage 1 of configs[3], 1 KB pieces, 18.40 -> 18.86; 64-byte alignment: no gain).
+#ifndef SMM_PACK_ALIGN
+#define SMM_PACK_ALIGN 16
+#endif
 __global__ __launch_bounds__(256) void smm_pack_count(int rows, int nct, const int *__restrict__ seg, int *__restrict__ units,
                                                       int *__restrict__ maxlen)
 {
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(256) void smm_pack_count(int rows, int nct, const i
         const int t = (int)(gid / rows), j = (int)(gid % rows);
         const int *sp = seg + (size_t)j * (nct + 1) + t;
         len = sp[1] - sp[0];
-        units[gid] = (len + ((len + 3) >> 2) + 1) & ~1;    // 16-byte pieces: the wide-chunk walk loads value pairs
+        units[gid] = (len + ((len + 3) >> 2) + (SMM_PACK_ALIGN - 1)) & ~(SMM_PACK_ALIGN - 1);   // pieces start on SMM_PACK_ALIGN x 8 bytes (>= 16: value pairs are loaded)
     }
     int mx = len;                                          // the longest piece decides which accumulate walk can run
     for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
