@@ -35,6 +35,25 @@ if len(sys.argv) > 1 and sys.argv[1] == "big":
         mats.append(sp.csr_matrix((dv, ix, ip), shape=(n, n)))
     torch.cuda.empty_cache()
     A, B = mats
+    # round 3: what the full-content operand key costs on this host (both operands, all three arrays each)
+    from sparse_matrix_mult_amd.matrix_ops import _operand_key, cache_stats
+    _, dt_key = timed(lambda: (_operand_key(A), _operand_key(B)))
+    _, dt_key2 = timed(lambda: (_operand_key(A), _operand_key(B)))
+    print(json.dumps({"operand_keys_both_operands_s": [round(dt_key, 4), round(dt_key2, 4)], "bytes_hashed": int(2 * (A.data.nbytes + A.indices.nbytes + A.indptr.nbytes))}), flush=True)
+    # round 3: same patterns, new values (in place): the values travel, the cached plan's numeric phase is replayed
+    pkg.clear_cache()
+    res = {}
+    C, res["first"] = timed(lambda: sparse_matrix_multiply(A, B))
+    del C
+    for label in ("new_values_1", "new_values_2"):
+        A.data *= 1.0001; B.data *= 0.9999
+        C, res[label] = timed(lambda: sparse_matrix_multiply(A, B))
+        del C
+    C, res["unchanged"] = timed(lambda: sparse_matrix_multiply(A, B))
+    del C
+    print(json.dumps({"config": "configs[1] through sparse_matrix_multiply(): first call / new values on the same patterns / unchanged",
+                      "seconds": {k: round(v, 3) for k, v in res.items()}, "cache_stats": dict(cache_stats)}), flush=True)
+    pkg.clear_cache()
     for fmt in ("sparse", "dense"):
         res = {}
         for label in ("cold", "warm", "warm2"):
