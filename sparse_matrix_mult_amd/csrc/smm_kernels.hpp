@@ -832,6 +832,7 @@ __global__ __launch_bounds__(256) void smm_ccs_row_work(int m, int n_slabs, int 
             if (lane == 0) {
                 const int64_t lo = (int64_t)s * ws;
                 int64_t cap = (ncols - lo) < ws ? (ncols - lo) : ws;
+                cap = cap > 0 ? cap : 0;                       // (exact-walk geometries may end in slabs beyond the last column)
                 if (sym) { const int64_t gi = row + row_offset; const int64_t from = gi > lo ? gi : lo; cap = lo + cap > from ? lo + cap - from : 0; }
                 ub[(size_t)s * m + row] = t < cap ? t : cap;
             }

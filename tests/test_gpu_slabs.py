@@ -95,3 +95,31 @@ def test_default_settings_keep_narrow_products_on_one_slab(ctx, oracle):
     """Below 63 456 columns nothing changes: one slab, the hash classes for rows with few products."""
     A, B = rand_csr(150, 120, 0.1, 41), rand_csr(120, 400, 0.1, 42)
     assert_csr_equal(_sparse(ctx, A, B, exact=True), oracle.sparse(arrays(A), arrays(B), 400), values="bits")
+
+
+@pytest.mark.parametrize("it", range(40))
+def test_slab_path_fuzz(ctx, oracle, it):
+    """Random tile width / waves / slab limit on random row-length distributions (the generator of the fuzz
+    campaign), both modes, symmetric on square cases."""
+    from test_gpu_fuzz_campaign import _rand_rows
+    r = np.random.default_rng(777000 + it)
+    cols = int(r.integers(64, 400)); waves = int(r.choice([4, 8, 16])); ws = int(r.integers(64, 1500))
+    m, k = int(r.integers(1, 600)), int(r.integers(1, 600))
+    n = m if it % 3 == 0 else int(r.integers(1, 6000))
+    A = _rand_rows(r, m, k, 10 ** r.uniform(0, 1.6), int(r.integers(0, 3)))
+    B = _rand_rows(r, k, n, 10 ** r.uniform(0, 2.0), int(r.integers(0, 3)))
+    if A is None or B is None or np.diff(B.indptr)[A.indices].sum() > 2e7:
+        pytest.skip("case larger than the budget")
+    ctx.tune_shared(cols, waves); ctx.tune(cols, min(waves, 8)); ctx.tune_symbolic(ws)
+    a, b = ctx.csr_from_scipy(A), ctx.csr_from_scipy(B)
+    try:
+        for sym in ((False, True) if m == n else (False,)):
+            want = oracle.sparse(arrays(A), arrays(B), n, symmetric=sym)
+            assert_csr_equal(ctx.spgemm_host(a, b, symmetric=sym, exact=True), want, values="bits")
+            gp, gi, gv = ctx.spgemm_host(a, b, symmetric=sym)
+            assert np.array_equal(np.asarray(gp, np.int64), np.asarray(want[0], np.int64)) and np.array_equal(gi, want[1])
+            mag = oracle.sparse(arrays(abs(A)), arrays(abs(B)), n, symmetric=sym)[2]
+            assert np.all(np.abs(gv - want[2]) <= 1e-12 * mag)
+    finally:
+        a.close(); b.close()
+        ctx.tune_shared(20000, 16); ctx.tune(18000, 8); ctx.tune_symbolic(0)
