@@ -193,6 +193,7 @@ extern "C" int smm_ctx_create(int device, void *hip_stream, smm_ctx **out)
     if (const char *e = getenv("SMM_SYM_WIDE")) c->sym_wide = atoi(e) != 0;
     if (const char *e = getenv("SMM_SYM_CCS")) c->sym_ccs = atoi(e) != 0;
     if (const char *e = getenv("SMM_PIECE_WALK")) c->piece_walk = atoi(e);
+    if (const char *e = getenv("SMM_SYM_MAX_WS")) c->sym_max_ws = std::max(0, std::min(atoi(e), (int)CCS_MAX_WS));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hip_stream == SMM_STREAM_DEFAULT) { c->stream = nullptr; c->own_stream = false; }   // the device's null stream
     else if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
@@ -1442,7 +1443,11 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         const bool dominant = c->sym_max_ws > 0 || hmax1 == 0 || 2 * (int64_t)sbin[2] >= m;
         if (c->sym_ccs && c->narrow_idx && wide && dominant && !safe && p->b_sorted && c->slab_mode != 2) {
             if (d_slists) pool_free(c, d_slists);
-            const int tps = std::max(1, std::min(8, ws_cap / p->g.wc));
+            // tiles per slab: as many as fit the slab limit (<= 8), but not so many that the marker bitmap leaves fewer
+            // than 28 waves per CU (configs[4] share: 3 tiles = 60 000 columns = 21 waves 12.4 ms, 2 tiles = 31 waves 11.7 ms)
+            int tps = std::max(1, std::min(8, ws_cap / p->g.wc));
+            if (c->sym_max_ws == 0)
+                while (tps > 1 && (160 * 1024) / ((((tps * p->g.wc + 31) / 32) + WAVE) * 4) < 28) --tps;
             p->tps = tps; p->ws = tps * p->g.wc; p->n_slabs = (p->g.nct + tps - 1) / tps;
             p->list16 = true;
             const int ns = p->n_slabs;
