@@ -439,9 +439,16 @@ extern "C" uint64_t smm_host_hash64(const void *ptr, int64_t nbytes)
     }
     if (nt <= 1) run(0, 1);
     else {
+        // (a thread that cannot be started -- resource limits -- must not throw across the C ABI: its blocks are
+        // hashed by this thread instead; the result does not depend on who hashes which block)
         std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; ++t) th.emplace_back(run, (size_t)t, (size_t)nt);
+        std::vector<unsigned> inline_lanes;
+        for (unsigned t = 1; t < nt; ++t) {
+            try { th.emplace_back(run, (size_t)t, (size_t)nt); }
+            catch (...) { inline_lanes.push_back(t); }
+        }
         run(0, nt);
+        for (unsigned t : inline_lanes) run(t, nt);
         for (auto &t : th) t.join();
     }
     uint64_t h = 0x3F84D5B5B5470917ull;
