@@ -773,6 +773,9 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, const int *__restrict
 // needs no lane mask, no entry count and no EXEC set-up: the padding lanes carry guard columns, which live in 64
 // words of their own behind the wave's bitmap (all ones: never "new"; one word per lane: they do not collide on
 // one address as the single guard word of smm_symbolic's idle lanes does).
+#ifndef SMM_CCS_ASM_STORES
+#define SMM_CCS_ASM_STORES 1
+#endif
 constexpr int CCS_CHUNK = 128;
 constexpr int CCS_MAX_WS = 63456;            // (ws / 32 + 64 guard words) * 32 + 31 must fit 16 bits
 __host__ __device__ __forceinline__ int ccs_guard_col(int bm_words, int p) { return (bm_words + (p >> 1)) * 32 + 31; }
@@ -935,8 +938,26 @@ __global__ __launch_bounds__(256) void smm_symbolic_ccs(int m, int n_slabs, cons
                             const unsigned long long ml = __ballot(nl_), mh = __ballot(nh_);
                             const unsigned at = __builtin_amdgcn_mbcnt_hi((unsigned)(mh >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mh,
                                                 __builtin_amdgcn_mbcnt_hi((unsigned)(ml >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ml, (unsigned)n))));
+#if SMM_CCS_ASM_STORES
+                            // hand-issued list stores: 32-bit byte offsets from the list's scalar base under the two ballot
+                            // masks -- no 64-bit address arithmetic, no branch around either store (the compiler's form: two
+                            // v_lshl_add_u64, a select, an add, two s_and_saveexec / s_cbranch_execz pairs).  Round 3, interleaved
+                            // A/B: smm_symbolic 5.37 -> 5.10 ms at configs[1], 12.0 -> 11.6 at the configs[4] share.
+                            {
+                                const unsigned off_lo = at << 1;
+                                const unsigned off_hi = (at + (nl_ ? 1u : 0u)) << 1;
+                                const unsigned packed = (unsigned)c[u] | ((unsigned)ch[u] << 16);
+                                asm volatile("s_mov_b64 exec, %4\n\t"
+                                             "global_store_short %0, %2, %3\n\t"
+                                             "s_mov_b64 exec, %5\n\t"
+                                             "global_store_short_d16_hi %1, %2, %3\n\t"
+                                             "s_mov_b64 exec, -1"
+                                             :: "v"(off_lo), "v"(off_hi), "v"(packed), "s"(out), "s"(ml), "s"(mh) : "memory");
+                            }
+#else
                             if (nl_) out[at] = (unsigned short)c[u];
                             if (nh_) out[at + (nl_ ? 1u : 0u)] = (unsigned short)ch[u];
+#endif
                             n += __popcll(ml) + __popcll(mh);
                         }
                     }
@@ -960,6 +981,9 @@ __global__ __launch_bounds__(256) void smm_symbolic_ccs(int m, int n_slabs, cons
             }
         }
         if (lane == 0) cnt[(size_t)s * m + row] = n;
+#if SMM_CCS_ASM_STORES
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the hand-issued list stores (read back just below)
+#endif
         // reset the marker for the next unit (sparsework.cpp:120-128: memset when the row is long, per entry otherwise)
         if (n >= bm_words) {
             for (int w = lane; w < bm_words; w += WAVE) bm[w] = 0;
