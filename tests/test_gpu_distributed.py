@@ -76,6 +76,10 @@ def test_bench_launches_its_own_ranks_and_gathers(tmp_path):
         line = json.loads(lines[0])
         assert line["n_gpus"] == 2 and line["value"] > 0 and line["unit"] == "nnz/s"
         assert ("all-gatherv" in line["config"]["workload"]) == bool(extra)
+        # round 3: who is in the job, and the collective part of a step on its own
+        assert line["rccl"]["backend"] == "gloo" and line["rccl"]["world"] == 2 and len(line["rccl"]["devices"]) == 2
+        assert line["rccl"]["distinct_devices"] == 1                     # the rehearsal puts both ranks on GPU 0
+        assert line["gather_ms" if extra else "exchange_ms"] >= 0.0
 
 
 def test_two_ranks_reassemble_the_single_device_csr():
