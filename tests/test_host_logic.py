@@ -125,3 +125,124 @@ def test_host_hash_is_the_same_for_every_thread_count_and_length_aware(monkeypat
     assert h(a[:-1]) != one and h(a[:1000]) != h(a[:1001])
     z = np.zeros(64, np.uint8)
     assert len({h(z[:n]) for n in range(1, 65)}) == 64                          # zero padding of the tail is not a collision
+
+
+# ---- operand / plan cache policy with a stub engine (the same code paths sparse_matrix_multiply() takes; no GPU)
+class _FakeHandle:
+    def __init__(self, ctx, m):
+        self.ctx, self.handle, self.nnz, self.rows, self.cols = ctx, object(), int(m.nnz), m.shape[0], m.shape[1]
+        self.values = np.array(m.data[:m.nnz], dtype=np.float64)
+        self.updates = 0
+
+    def update_values(self, data):
+        assert len(data) == self.nnz
+        self.values = np.array(data, dtype=np.float64); self.updates += 1
+
+    def device_bytes(self):
+        return 12 * self.nnz + 1000 if self.handle else 0
+
+    def close(self):
+        self.handle = None
+
+
+class _FakePlan:
+    def __init__(self, a, b):
+        self.a, self.b, self.handle, self.nnz = a, b, object(), 1
+
+    def device_bytes(self):
+        return 5000 if self.handle else 0
+
+    def close(self):
+        self.handle = None
+
+
+class _FakeCtx:
+    def __init__(self):
+        self.uploads, self.plans = 0, 0
+
+    def csr_from_scipy(self, m):
+        self.uploads += 1
+        return _FakeHandle(self, m)
+
+    def spgemm_plan(self, a, b, symmetric=False, exact=False):
+        self.plans += 1
+        return _FakePlan(a, b)
+
+
+@pytest.fixture()
+def cache():
+    from sparse_matrix_mult_amd import matrix_ops as mo
+    mo.clear_cache()
+    saved = (mo._cache_entries, mo._cache_max_bytes, mo._plan_entries)
+    mo._cache_entries, mo._cache_max_bytes, mo._plan_entries = 4, 1 << 40, 2
+    mo.cache_stats.clear()
+    yield mo
+    mo.clear_cache()
+    mo._cache_entries, mo._cache_max_bytes, mo._plan_entries = saved
+
+
+def _rand(m, n, seed):
+    return sp.random(m, n, density=0.1, format="csr", random_state=np.random.default_rng(seed))
+
+
+def test_cache_policy_hit_update_and_plan_replay(cache):
+    mo, ctx = cache, _FakeCtx()
+    A, B = _rand(30, 40, 1), _rand(40, 50, 2)
+
+    def call(a, b):
+        ka, kb = mo._operand_key(a), mo._operand_key(b)
+        la = mo._acquire(ctx, a, ka, protect=(kb[0],)); lb = mo._acquire(ctx, b, kb)
+        plan, release = mo._plan_for(ctx, la, lb, False, False)
+        vals = (la.handle.values.copy(), lb.handle.values.copy())
+        release(); lb.release(); la.release()
+        return plan, vals
+
+    p1, _ = call(A, B)
+    assert (ctx.uploads, ctx.plans) == (2, 1) and len(mo._cache) == 2 and len(mo._plans) == 1
+    p2, _ = call(A, B)                                           # unchanged: both hit, plan replayed
+    assert p2 is p1 and (ctx.uploads, ctx.plans) == (2, 1) and mo.cache_stats["hit"] == 2 and mo.cache_stats["plan_hit"] == 1
+    B.data[7] += 1.0                                             # in-place edit of one value: seen, values only
+    p3, (va, vb) = call(A, B)
+    assert p3 is p1 and ctx.uploads == 2 and mo.cache_stats["values_update"] == 1 and np.array_equal(vb, B.data)
+    B2 = B.copy(); B2.data *= 2                                  # equal pattern in other arrays: same entry, values replaced
+    p4, (va, vb) = call(A, B2)
+    assert p4 is p1 and ctx.uploads == 2 and np.array_equal(vb, B2.data)
+    B.indices[3] = (B.indices[3] + 1) % 50                       # structural edit in place: a new operand, a new plan
+    p5, _ = call(A, B)
+    assert p5 is not p1 and ctx.uploads == 3 and ctx.plans == 2
+
+
+def test_cache_policy_limits_orphans_and_leases(cache):
+    import gc
+    mo, ctx = cache, _FakeCtx()
+    B = _rand(40, 50, 2)
+    mats = [_rand(30, 40, 10 + i) for i in range(6)]
+    for A in mats:
+        la = mo._acquire(ctx, A); lb = mo._acquire(ctx, B); lb.release(); la.release()
+    assert len(mo._cache) == 4 and mo._operand_key(B)[0] in mo._cache          # LRU: B was used every time and stays
+    # an entry in use is neither evicted nor updated in place
+    held = mo._acquire(ctx, mats[5])
+    old_values = held.handle.values.copy()
+    C = mats[5].copy(); C.data += 1.0
+    other = mo._acquire(ctx, C)                                                 # same pattern, other values, entry busy
+    assert other.entry is None and np.array_equal(held.handle.values, old_values) and held.handle.updates == 0
+    other.release(); held.release()
+    # orphans (their arrays are gone) are purged at the next miss, not the operand about to be looked up
+    mo.clear_cache()
+    T = _rand(30, 40, 99)
+    lt = mo._acquire(ctx, T); lt.release()
+    pat = mo._operand_key(T)[0]
+    T2 = T.copy()                                                               # equal content in other arrays
+    del T; gc.collect()
+    assert mo._cache[pat].orphaned()
+    lx = mo._acquire(ctx, mats[0], protect=(pat,))                             # a miss that protects T's pattern (the call's other operand)
+    assert pat in mo._cache
+    l2 = mo._acquire(ctx, T2); assert l2.entry is mo._cache[pat] and not l2.entry.orphaned()
+    l2.release(); lx.release()
+    del T2; gc.collect()
+    ly = mo._acquire(ctx, mats[1]); ly.release()                                # no protection now: the orphan goes
+    assert pat not in mo._cache
+    # byte cap: plans go first, then idle entries
+    mo._cache_max_bytes = 1
+    lz = mo._acquire(ctx, mats[2]); lz.release()
+    assert len(mo._cache) == 0 and len(mo._plans) == 0
