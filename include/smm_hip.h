@@ -34,7 +34,11 @@ enum smm_status {
     SMM_ERR_ALLOC     = -3,   /* hipMalloc / malloc failed                              */
     SMM_ERR_HIP       = -4,   /* a HIP runtime call or kernel launch failed             */
     SMM_ERR_OVERFLOW  = -5,   /* result does not fit the legacy int32 ABI               */
-    SMM_ERR_UNSUPPORTED = -6  /* the device does not behave as SMM_EXACT needs (smm_ctx_exact_selftest) */
+    SMM_ERR_UNSUPPORTED = -6, /* the device does not behave as SMM_EXACT needs (smm_ctx_exact_selftest) */
+    SMM_ERR_INTERNAL  = -7    /* inconsistent plan metadata caught by a kernel's bounds clamp or by the plan
+                                 checker: a defect of this library, reported instead of a hang or a fault
+                                 (reference convention: message + early return, src/sparsework.cpp:33-36,
+                                 src/sparse_sparse_sparse.cpp:257-262)                                   */
 };
 
 enum smm_flags {
@@ -73,7 +77,13 @@ const char *smm_last_error(void);                /* thread-local message of the 
 #define SMM_STREAM_DEFAULT ((void *)(intptr_t)-1)
 int  smm_ctx_create(int device, void *hip_stream, smm_ctx **out);
 void smm_ctx_destroy(smm_ctx *ctx);
+/* Waits for the context's stream and reports what the kernels recorded since the last report: SMM_ERR_INTERNAL when
+ * a numeric kernel met inconsistent plan metadata (see smm_plan_check) -- the way an error of the asynchronous
+ * smm_spgemm_numeric reaches the caller. */
 int  smm_ctx_synchronize(smm_ctx *ctx);
+/* 1: every smm_spgemm_symbolic ends with smm_plan_check (also: env SMM_CHECK=1 when the context is created).  Off by
+ * default: the checker streams the ordered lists once more (~2 ms at 50k x 50k); the kernels' own clamps are always on. */
+int  smm_ctx_set_check(smm_ctx *ctx, int enable);
 /* Per-kernel timing with HIP events on the context's stream (bench.py's roofline leg).
  * enable=1 starts recording; smm_ctx_kernel_time returns the accumulated milliseconds and
  * launch count of the named kernel since the last reset (name as printed by rocprofv3,
@@ -178,6 +188,16 @@ int  smm_spgemm_numeric_host_i64(smm_ctx *ctx, smm_plan *plan,
                                  int64_t *c_indptr, int64_t *c_indices, double *c_data);
 /* Only the int64 row pointer of the planned product (device->host, a.rows+1 entries). */
 int  smm_plan_indptr_host(smm_ctx *ctx, smm_plan *plan, int64_t *c_indptr);
+/* Verify every invariant of the plan that the numeric phase relies on (list capacities non-negative and not
+ * overlapping, row counts = row pointer, start slots monotone, list entries in range, sub-run tables consistent with
+ * the lists, tile by tile) on the device.  SMM_OK, or SMM_ERR_INTERNAL with the first offending row in
+ * smm_last_error().  The numeric kernels additionally clamp everything they read from a plan, always: a table that
+ * slipped through can cost a row its values, never a store outside the row, a hang or a fault. */
+int  smm_plan_check(smm_ctx *ctx, smm_plan *plan);
+/* TEST HOOK: damage one piece of the plan's metadata in HBM (kind 1..8: reversed / out-of-row sub-run, tail
+ * descriptor, row count, list entry, slab sub-run, start slot, negative capacity) so that the error path above can
+ * be exercised; the plan is to be destroyed afterwards. */
+int  smm_plan_inject_fault(smm_ctx *ctx, smm_plan *plan, int kind);
 int64_t smm_plan_nnz(const smm_plan *plan);
 int64_t smm_plan_device_bytes(const smm_plan *plan);   /* HBM scratch the plan holds (lists, sub-run table, ...) */
 void smm_plan_destroy(smm_plan *plan);

@@ -22,6 +22,7 @@ SMM_EXACT = 4
 SMM_MIRROR = 8
 SMM_ERR_ALLOC = -3
 SMM_ERR_UNSUPPORTED = -6
+SMM_ERR_INTERNAL = -7
 
 _c_i64 = ctypes.c_int64
 _vp = ctypes.c_void_p
@@ -45,6 +46,9 @@ V2_PROTOTYPES = {
     "smm_ctx_tune_narrow": (ctypes.c_int, [_vp, ctypes.c_int]),
     "smm_ctx_exact_selftest": (ctypes.c_int, [_vp, ctypes.c_int]),
     "smm_ctx_tune_symbolic": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "smm_ctx_set_check": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "smm_plan_check": (ctypes.c_int, [_vp, _vp]),
+    "smm_plan_inject_fault": (ctypes.c_int, [_vp, _vp, ctypes.c_int]),
     "smm_csr_from_host": (ctypes.c_int, [_vp, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _pp]),
     "smm_csr_from_device": (ctypes.c_int, [_vp, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _pp]),
     "smm_csr_destroy": (None, [_vp]),

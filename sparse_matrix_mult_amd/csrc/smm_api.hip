@@ -94,7 +94,9 @@ struct smm_ctx {
     void *pin[PIN_SLOTS] = {nullptr};
     hipEvent_t pin_ev[PIN_SLOTS] = {nullptr};
     int exact_checked = 0;           // SMM_EXACT guard (smm_ctx_exact_selftest): 0 not run yet, 1 passed, -1 failed
+    int check = 0;                   // 1: every symbolic phase ends with the plan checker (env SMM_CHECK, smm_ctx_set_check)
     unsigned *d_flags = nullptr;     // [0] validation flags; +64: int -1 and +128: double 0 read by idle lanes
+    unsigned *d_err = nullptr;       // plan error word: [0] PLAN_ERR_* bits, [1] lowest row that tripped one (kernels' always-on clamps, plan checker)
     std::recursive_mutex mu;         // every entry point that touches the context takes it: calls from
                                      // several host threads on one context serialise (one stream anyway)
 };
@@ -194,6 +196,7 @@ extern "C" int smm_ctx_create(int device, void *hip_stream, smm_ctx **out)
     if (const char *e = getenv("SMM_SYM_CCS")) c->sym_ccs = atoi(e) != 0;
     if (const char *e = getenv("SMM_PIECE_WALK")) c->piece_walk = atoi(e);
     if (const char *e = getenv("SMM_SYM_MAX_WS")) c->sym_max_ws = std::max(0, std::min(atoi(e), (int)CCS_MAX_WS));
+    if (const char *e = getenv("SMM_CHECK")) c->check = atoi(e) != 0;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hip_stream == SMM_STREAM_DEFAULT) { c->stream = nullptr; c->own_stream = false; }   // the device's null stream
     else if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
@@ -213,6 +216,14 @@ extern "C" int smm_ctx_create(int device, void *hip_stream, smm_ctx **out)
             return fail(SMM_ERR_HIP, "hipMemcpy of the context constants failed");
         }
     }
+    {
+        const unsigned clean[2] = {0u, 0xffffffffu};
+        if (hipMalloc((void **)&c->d_err, 64) != hipSuccess || hipMemcpy(c->d_err, clean, sizeof(clean), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(c->d_err); (void)hipFree(c->d_flags); delete c;
+            return fail(SMM_ERR_ALLOC, "hipMalloc of the context's error word failed");
+        }
+    }
     *out = c;
     return SMM_OK;
 }
@@ -226,6 +237,7 @@ extern "C" void smm_ctx_destroy(smm_ctx *c)
     for (auto &b : c->pool) (void)hipFree(b.p);
     for (auto &kv : c->live) (void)hipFree(kv.first);
     (void)hipFree(c->d_flags);
+    (void)hipFree(c->d_err);
     for (int i = 0; i < smm_ctx::PIN_SLOTS; ++i) {
         if (c->pin[i]) (void)hipHostFree(c->pin[i]);
         if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]);
@@ -234,11 +246,40 @@ extern "C" void smm_ctx_destroy(smm_ctx *c)
     delete c;
 }
 
+// Fetch-and-clear the context's plan error word (what the kernels' always-on clamps and the plan checker record);
+// synchronises the stream.  A non-zero word means plan metadata was inconsistent: the result of the product that
+// tripped it is not to be trusted, and the caller gets SMM_ERR_INTERNAL -- never a hang or a fault.
+static int take_plan_error(smm_ctx *c, const char *where)
+{
+    unsigned h[2] = {0u, 0u};
+    HIPCHK(hipMemcpyAsync(h, c->d_err, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (!h[0]) return SMM_OK;
+    const unsigned clean[2] = {0u, 0xffffffffu};
+    HIPCHK(hipMemcpyAsync(c->d_err, clean, sizeof(clean), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    static const char *names[] = {"sub-run bounds", "tail descriptor", "slab sub-run table", "start slots", "hash look-up",
+                                  "list capacity", "row counts", "list entries"};
+    std::string what;
+    for (int b = 0; b < 8; ++b)
+        if (h[0] & (1u << b)) { if (!what.empty()) what += ", "; what += names[b]; }
+    return fail(SMM_ERR_INTERNAL, "%s: inconsistent plan metadata (%s; first at row %u of A) -- the result of this product is not valid; "
+                                  "please report this with the operands (SMM_CHECK=1 verifies every plan)", where, what.c_str(), h[1]);
+}
+
 extern "C" int smm_ctx_synchronize(smm_ctx *c)
 {
     if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
     CTX_LOCK(c);
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipSetDevice(c->device));
+    return take_plan_error(c, "smm_ctx_synchronize");       // (synchronises the stream)
+}
+
+extern "C" int smm_ctx_set_check(smm_ctx *c, int enable)
+{
+    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CTX_LOCK(c);
+    c->check = enable != 0;
     return SMM_OK;
 }
 
@@ -532,7 +573,33 @@ static int download(smm_ctx *c, void *dst, const void *src_dev, size_t bytes, bo
         }
     };
     std::vector<std::thread> threads;
-    for (int w = 0; w < W; ++w) threads.emplace_back(worker, w);
+    bool spawned = true;
+    try {
+        for (int w = 0; w < W; ++w) threads.emplace_back(worker, w);
+    } catch (...) {                                     // (resource limits: nothing may throw across the C ABI)
+        spawned = false;
+    }
+    if (!spawned) {
+        // the workers that did start are told to stop; this thread moves the chunks alone, one at a time
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t k = 0; k < nchunks; ++k) issued[k] = 2;
+        }
+        cv.notify_all();
+        for (auto &t : threads) t.join();
+        for (size_t i = 0; i < nchunks; ++i) {
+            const size_t off = i * CH, len = std::min(CH, bytes - off);
+            HIPCHK(hipMemcpyAsync(c->pin[0], (const char *)src_dev + off, len, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (!widen) memcpy((char *)dst + off, c->pin[0], len);
+            else {
+                const int32_t *sp = (const int32_t *)c->pin[0];
+                int64_t *dp = (int64_t *)dst + off / sizeof(int32_t);
+                for (size_t k = 0; k < len / sizeof(int32_t); ++k) dp[k] = sp[k];
+            }
+        }
+        return SMM_OK;
+    }
     hipError_t err = hipSuccess;
     for (size_t i = 0; i < nchunks; ++i) {
         if (i >= (size_t)R) {                                       // the slot's previous chunk must have left it
@@ -933,6 +1000,7 @@ static int launch_numeric(smm_ctx *c, NumericArgs &args, bool sym, int nw, bool 
     if (args.m <= 0) return SMM_OK;
     args.dummy_idx = (const int *)((const char *)c->d_flags + 64);
     args.dummy_val = (const double *)((const char *)c->d_flags + 128);
+    args.err = c->d_err;
 #define SMM_CASE(S, N, X) \
     if (sym == S && nw == N && exact == X) return launch_numeric_t<OUT, S, N, X>(c, args);
     SMM_CASE(false, 1, true) SMM_CASE(true, 1, true) SMM_CASE(false, 2, true) SMM_CASE(true, 2, true)
@@ -944,6 +1012,7 @@ static int launch_numeric(smm_ctx *c, NumericArgs &args, bool sym, int nw, bool 
     return fail(SMM_ERR_INVALID, "unsupported numeric configuration");
 }
 
+constexpr size_t LIST_SLACK = (size_t)1 << 17;      // entries behind the ordered lists (see smm_spgemm_symbolic)
 #ifndef SMM_CCS_UNROLL
 #define SMM_CCS_UNROLL 8        // chunk loads in flight per wave of smm_symbolic_ccs (configs[1]: 2: 6.7, 4: 5.5, 8: 5.2 ms)
 #endif
@@ -976,6 +1045,7 @@ struct smm_plan {
     SlabGeom sg{};
     smm_csr::SlabCache slab{0, 0, nullptr, nullptr, nullptr};
     int *d_rowcnt = nullptr;       // m
+    int64_t total_cap = 0;         // sum of the list capacities (= d_ub_off's last entry)
     int *d_lists = nullptr;        // 3 x m: rows of the small / medium / dense bins
     int n_bin[3] = {0, 0, 0};
     int64_t *d_cptr = nullptr;     // m+1
@@ -1374,6 +1444,78 @@ static int launch_symbolic_w(smm_ctx *c, smm_plan *p, int words, unsigned *gbm, 
     return SMM_OK;
 }
 
+// The plan checker (smm_plan_check_* in smm_kernels.hpp): every invariant the numeric phase relies on, verified on the
+// device; violations come back as SMM_ERR_INTERNAL through the context's error word.
+static int plan_check(smm_ctx *c, smm_plan *p)
+{
+    const int64_t m = p->m;
+    if (m == 0 || !p->d_ub_off || !p->d_rowcnt) return take_plan_error(c, "smm_plan_check");      // zero operand: nothing was planned
+    const smm_csr *a = p->a;
+    const int grid = (int)std::min<int64_t>((m + 3) / 4, 16384);
+    const bool slabs = p->d_scnt != nullptr;
+    const int ns = slabs ? p->n_slabs : 1;
+    const int *cnt = slabs ? p->d_scnt : p->d_rowcnt;
+    if (p->list16)
+        LAUNCH(c, "smm_plan_check", smm_plan_check_rows<unsigned short>, grid, 256, 0, (int)m, ns, slabs ? p->ws : (int)p->ncols, (int)p->ncols,
+               (int64_t)a->nnz, p->total_cap, a->ptr, (const int64_t *)p->d_ub_off, cnt, (const int *)p->d_rowcnt, (const int64_t *)p->d_cptr,
+               (const unsigned *)p->d_P, (const unsigned short *)p->d_tmp, c->d_err);
+    else
+        LAUNCH(c, "smm_plan_check", smm_plan_check_rows<int>, grid, 256, 0, (int)m, ns, (int)p->ncols, (int)p->ncols,
+               (int64_t)a->nnz, p->total_cap, a->ptr, (const int64_t *)p->d_ub_off, cnt, (const int *)p->d_rowcnt, (const int64_t *)p->d_cptr,
+               (const unsigned *)p->d_P, (const int *)p->d_tmp, c->d_err);
+    LAUNCH_CHECK();
+    CHK(take_plan_error(c, "smm_plan_check"));          // the table checks below walk the lists through what was just verified
+    const int nd = p->n_bin[2];
+    if (nd > 0 && p->d_lists) {
+        const int *rows = p->d_lists + 2 * m;
+        const int rgrid = (int)std::min<int64_t>((nd + 3) / 4, 16384);
+        if (p->d_runs2)
+            LAUNCH(c, "smm_plan_check", smm_plan_check_runs2, rgrid, 256, 0, nd, (int)m, p->n_slabs, p->tps, p->g.nct, p->g.wc, (int64_t)a->nnz, rows,
+                   a->ptr, (const int64_t *)p->d_ub_off, (const int *)p->d_scnt, (const int64_t *)p->d_cptr, (const unsigned *)p->d_P,
+                   (const unsigned short *)p->d_tmp, (const uint2 *)p->d_runs2, c->d_err);
+        else if (p->d_runs && p->list16)
+            LAUNCH(c, "smm_plan_check", smm_plan_check_runs<unsigned short>, rgrid, 256, 0, nd, p->g.nct, p->g.wc, rows, a->ptr,
+                   (const int64_t *)p->d_ub_off, (const int *)p->d_rowcnt, (const unsigned *)p->d_P, (const unsigned short *)p->d_tmp,
+                   (const unsigned *)p->d_runs, (const int2 *)p->d_tail, c->d_err);
+        else if (p->d_runs)
+            LAUNCH(c, "smm_plan_check", smm_plan_check_runs<int>, rgrid, 256, 0, nd, p->g.nct, p->g.wc, rows, a->ptr,
+                   (const int64_t *)p->d_ub_off, (const int *)p->d_rowcnt, (const unsigned *)p->d_P, (const int *)p->d_tmp,
+                   (const unsigned *)p->d_runs, (const int2 *)p->d_tail, c->d_err);
+        LAUNCH_CHECK();
+    }
+    return take_plan_error(c, "smm_plan_check");
+}
+
+extern "C" int smm_plan_check(smm_ctx *c, smm_plan *p)
+{
+    if (!c || !p || p->ctx != c) return fail(SMM_ERR_INVALID, "bad plan/context");
+    CTX_LOCK(c);
+    HIPCHK(hipSetDevice(c->device));
+    return plan_check(c, p);
+}
+
+// Test hook: damage one piece of the plan's metadata on the device (kinds: smm_plan_corrupt in smm_kernels.hpp).
+extern "C" int smm_plan_inject_fault(smm_ctx *c, smm_plan *p, int kind)
+{
+    if (!c || !p || p->ctx != c) return fail(SMM_ERR_INVALID, "bad plan/context");
+    CTX_LOCK(c);
+    HIPCHK(hipSetDevice(c->device));
+    if (kind < 1 || kind > 8) return fail(SMM_ERR_INVALID, "fault kind must be in [1,8]");
+    if (p->nnz == 0 || !p->d_lists) return fail(SMM_ERR_INVALID, "fault injection needs a plan with a non-empty result");
+    if ((kind <= 3 && !p->d_runs) || (kind == 6 && !p->d_runs2)) return fail(SMM_ERR_INVALID, "this plan has no such table");
+    // the first row of the tile bin (the tables exist for those rows only), else of the medium / small hash bin
+    const int bin = p->n_bin[2] > 0 ? 2 : (p->n_bin[1] > 0 ? 1 : 0);
+    if (p->n_bin[bin] == 0 || (bin != 2 && (kind <= 3 || kind == 6))) return fail(SMM_ERR_INVALID, "no row to damage for this fault kind");
+    int row = 0;
+    HIPCHK(hipMemcpyAsync(&row, p->d_lists + (size_t)bin * p->m, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL(smm_plan_corrupt, dim3(1), dim3(64), 0, c->stream, kind, row, p->g.nct, (int64_t)p->a->nnz, p->a->ptr, p->d_ub_off,
+                       p->d_rowcnt, p->d_P, p->d_tmp, p->list16 ? 1 : 0, p->d_runs, p->d_tail, p->d_runs2);
+    LAUNCH_CHECK();
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SMM_OK;
+}
+
 extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t a_row_offset,
                                    smm_plan **plan, int64_t *nnz_out)
 {
@@ -1477,9 +1619,12 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
                 if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "slab row work: %s", hipGetErrorString(e)); }
             }
             pool_free(c, d_ubs);
+            p->total_cap = total_ub;
             {
+                // (+ slack: a list longer than its capacity -- a defect the plan checker reports -- and a sub-run table that
+                // points past a list must still stay inside this allocation)
                 char *tmp = nullptr;
-                PCHK(pool_get(c, (size_t)std::max<int64_t>(total_ub, 1) * 2, &tmp));
+                PCHK(pool_get(c, ((size_t)std::max<int64_t>(total_ub, 1) + LIST_SLACK) * 2, &tmp));
                 p->d_tmp = tmp;
             }
             PCHK(pool_get(c, (size_t)a->nnz * ns, &p->d_P));
@@ -1542,10 +1687,11 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
                 const int nd = p->n_bin[2];
                 LAUNCH(c, "smm_runs", smm_runs_slab, std::min<int64_t>((nd + 3) / 4, 65536), 256, 0, nd, (int)m, ns, tps, p->g.nct, p->g.wc,
                        (int64_t)a->nnz, (const int *)(p->d_lists + 2 * m), a->ptr, (const int64_t *)p->d_ub_off, (const int *)p->d_scnt,
-                       (const unsigned *)p->d_P, (const unsigned short *)p->d_tmp, p->d_dst0, p->d_runs2);
+                       (const unsigned *)p->d_P, (const unsigned short *)p->d_tmp, p->d_dst0, p->d_runs2, c->d_err);
                 hipError_t e = hipGetLastError();
                 if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "smm_runs_slab: %s", hipGetErrorString(e)); }
             }
+            if (c->check) PCHK(plan_check(c, p));
             if (nnz_out) *nnz_out = p->nnz;
             *plan = p;
             return SMM_OK;
@@ -1553,9 +1699,10 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     }
     p->list16 = c->narrow_idx && p->ncols < 65535 && b->cols < 65535;
     if (p->list16) PCHK(ensure_idx16(c, b));
+    p->total_cap = total_ub;
     {
         char *tmp = nullptr;
-        PCHK(pool_get(c, (size_t)std::max<int64_t>(total_ub, 1) * (p->list16 ? 2 : 4), &tmp));
+        PCHK(pool_get(c, ((size_t)std::max<int64_t>(total_ub, 1) + std::max<size_t>(LIST_SLACK, (size_t)p->ncols)) * (p->list16 ? 2 : 4), &tmp));
         p->d_tmp = tmp;
     }
     PCHK(pool_get(c, (size_t)a->nnz, &p->d_P));
@@ -1674,13 +1821,14 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         const int rgrid = (int)std::min<int64_t>((nd + 3) / 4, 65536);
         if (p->list16)
             LAUNCH(c, "smm_runs", smm_runs<unsigned short>, rgrid, 256, 0, nd, p->g.nct, p->g.wc, (const int *)(p->d_lists + 2 * m), a->ptr,
-                   p->d_ub_off, p->d_rowcnt, p->d_P, (const unsigned short *)p->d_tmp, p->d_runs, p->d_tail);
+                   p->d_ub_off, p->d_rowcnt, p->d_P, (const unsigned short *)p->d_tmp, p->d_runs, p->d_tail, c->d_err);
         else
             LAUNCH(c, "smm_runs", smm_runs<int>, rgrid, 256, 0, nd, p->g.nct, p->g.wc, (const int *)(p->d_lists + 2 * m), a->ptr,
-                   p->d_ub_off, p->d_rowcnt, p->d_P, (const int *)p->d_tmp, p->d_runs, p->d_tail);
+                   p->d_ub_off, p->d_rowcnt, p->d_P, (const int *)p->d_tmp, p->d_runs, p->d_tail, c->d_err);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "smm_runs: %s", hipGetErrorString(e)); }
     }
+    if (c->check) PCHK(plan_check(c, p));
 #undef PCHK
     if (nnz_out) *nnz_out = p->nnz;
     *plan = p;
@@ -1709,6 +1857,7 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
         H.ub_off = p->d_ub_off; H.tmp_idx = p->d_tmp; H.list16 = p->list16 ? 1 : 0;
         H.dummy_idx = (const int *)((const char *)c->d_flags + 64);
         H.dummy_val = (const double *)((const char *)c->d_flags + 128);
+        H.err = c->d_err;
         if (p->n_bin[0] > 0) {      // one wave per row, four rows per workgroup (always reference order)
             H.nrows = p->n_bin[0]; H.rowlist = p->d_lists;
             const int grid = (int)std::min<int64_t>((H.nrows + 3) / 4, (int64_t)c->n_cu * 32);
@@ -1759,6 +1908,7 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
                 A.c_dense = scratch; A.ldc = p->ncols;
                 A.dummy_idx = (const int *)((const char *)c->d_flags + 64);
                 A.dummy_val = (const double *)((const char *)c->d_flags + 128);
+                A.err = c->d_err;
                 rc = sym ? launch_numeric_t<OUT_SPARSE, true, 16, false, true>(c, A) : launch_numeric_t<OUT_SPARSE, false, 16, false, true>(c, A);
             }
             pool_free(c, scratch);          // stream-ordered: only work queued behind the emission can get it
@@ -1824,6 +1974,7 @@ static int numeric_host(smm_ctx *c, smm_plan *p, int64_t *c_indptr, void *c_indi
     if (rc == SMM_OK && nnz > 0) rc = download(c, c_data, dv, (size_t)nnz * sizeof(double));
     (void)hipStreamSynchronize(c->stream);
     pool_free(c, dp); pool_free(c, di); pool_free(c, dv);
+    if (rc == SMM_OK) rc = take_plan_error(c, "smm_spgemm_numeric");       // what the kernels' clamps recorded, if anything
     return rc;
 }
 

@@ -32,6 +32,31 @@ enum { OUT_SPARSE = 0, OUT_DENSE = 1 };
 // flag bits written by smm_validate
 enum { CSR_BAD = 1, CSR_UNSORTED = 2, CSR_HAS_EQUAL = 4 };
 
+// Plan metadata is produced by one kernel and trusted by the next (capacities -> lists -> P -> sub-run tables ->
+// epilogue).  An inconsistency there must come back to the caller as SMM_ERR_INTERNAL, never as a hang or a fault
+// (the reference's convention: message + early return, sparsework.cpp:33-36, sparse_sparse_sparse.cpp:257-262).
+// Two layers: (1) always on -- every consumer clamps what it reads (unsigned differences, positions against the row
+// length) so that a wrong table can only produce a wrong row, and records the fact in the context's error word;
+// (2) smm_plan_check_* below verify the whole plan (SMM_CHECK=1 / smm_ctx_set_check, and every test).
+// err[0] = OR of these bits, err[1] = lowest row (local index of A) that tripped one.
+enum {
+    PLAN_ERR_RUNS = 1,      // sub-run table: r1 < r0, or beyond the row
+    PLAN_ERR_TAIL = 2,      // tail descriptor outside the row's steps / positions
+    PLAN_ERR_RUNS2 = 4,     // slab table: source / length / destination outside the list or the row
+    PLAN_ERR_P = 8,         // start slots not monotone, or beyond the list length
+    PLAN_ERR_HASH = 16,     // a column of the product is not in the row's list (hash kernels)
+    PLAN_ERR_CAP = 32,      // negative / overlapping list capacity, or a list longer than its capacity
+    PLAN_ERR_COUNT = 64,    // row counts do not add up to the row pointer
+    PLAN_ERR_LIST = 128,    // a list entry is not a column of the (slab of the) result, or not in its sub-run's tile
+};
+#ifndef SMM_CLAMPS
+#define SMM_CLAMPS 1       // 0: a diagnostic build without the always-on clamps (A/B of their cost; never shipped)
+#endif
+__device__ __forceinline__ void plan_err(unsigned *err, unsigned bit, int row) {
+    atomicOr(err, bit);
+    atomicMin(err + 1, (unsigned)row);
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
 __device__ __forceinline__ int rl(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
@@ -1018,7 +1043,7 @@ __global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc, const in
                                                 const int *__restrict__ rowcnt,
                                                 const unsigned *__restrict__ P,
                                                 const LT *__restrict__ tmp_idx,
-                                                unsigned *__restrict__ runs, int2 *__restrict__ tail)
+                                                unsigned *__restrict__ runs, int2 *__restrict__ tail, unsigned *__restrict__ err)
 {
     __shared__ int win_all[4][RUNS_WIN];
     constexpr int NV = RUNS_WIN / WAVE;            // window elements per lane
@@ -1057,8 +1082,15 @@ __global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc, const in
         for (int eb = a0; eb < e0; eb += WAVE) {
             const int e = eb + lane;
             const bool valid = e < e0;
-            const unsigned p0 = valid ? P[e] : total;
-            const unsigned p1 = (valid && e + 1 < a1) ? P[e + 1] : total;
+            unsigned p0 = valid ? P[e] : total;
+            unsigned p1 = (valid && e + 1 < a1) ? P[e + 1] : total;
+            // (always on: start slots are another kernel's output -- a value beyond the list or a step that ends before
+            // it starts would turn the window loop below into 2^32 / RUNS_WIN iterations)
+            if (p0 > total || p1 > total || p1 < p0) {
+                plan_err(err, PLAN_ERR_P, row);
+                p0 = p0 < total ? p0 : total;
+                p1 = p1 < p0 ? p0 : (p1 < total ? p1 : total);
+            }
             unsigned *r = runs + (size_t)(valid ? e : e0 - 1) * (nct + 1);
             int tcur = 1;                           // next boundary this lane has to place
             if (valid) {
@@ -1121,7 +1153,7 @@ __global__ __launch_bounds__(256) void smm_runs_slab(int nrows, int m, int n_sla
                                                      const int *__restrict__ rowlist, const int *__restrict__ a_ptr,
                                                      const int64_t *__restrict__ list_off, const int *__restrict__ scnt,
                                                      const unsigned *__restrict__ P, const unsigned short *__restrict__ tmp,
-                                                     unsigned *__restrict__ dst0, uint2 *__restrict__ runs2)
+                                                     unsigned *__restrict__ dst0, uint2 *__restrict__ runs2, unsigned *__restrict__ err)
 {
     __shared__ int win_all[4][RUNS_WIN];
     constexpr int NV = RUNS_WIN / WAVE;
@@ -1134,7 +1166,9 @@ __global__ __launch_bounds__(256) void smm_runs_slab(int nrows, int m, int n_sla
         auto cnt_of = [&](int s, int e) -> unsigned {         // c_s[e] for a valid entry e of this row
             const unsigned *Ps = P + (size_t)s * nnzA;
             const unsigned q1 = e + 1 < a1 ? Ps[e + 1] : (unsigned)scnt[(size_t)s * m + row];
-            return q1 - Ps[e];
+            const unsigned q0 = Ps[e];
+            return q1 >= q0 ? q1 - q0 : 0u;     // (a step that ends before it starts is recorded in pass B; a length beyond
+                                                //  the list only misplaces dst, which the epilogue checks against the row)
         };
         // A. D[e]: where step e starts in the row of C
         unsigned carry = 0;
@@ -1168,8 +1202,13 @@ __global__ __launch_bounds__(256) void smm_runs_slab(int nrows, int m, int n_sla
             for (int eb = a0; eb < a1; eb += WAVE) {
                 const int e = eb + lane;
                 const bool valid = e < a1;
-                const unsigned p0 = valid ? Ps[e] : total;
-                const unsigned p1 = (valid && e + 1 < a1) ? Ps[e + 1] : total;
+                unsigned p0 = valid ? Ps[e] : total;
+                unsigned p1 = (valid && e + 1 < a1) ? Ps[e + 1] : total;
+                if (p0 > total || p1 > total || p1 < p0) {      // always on, see smm_runs
+                    plan_err(err, PLAN_ERR_P, row);
+                    p0 = p0 < total ? p0 : total;
+                    p1 = p1 < p0 ? p0 : (p1 < total ? p1 : total);
+                }
                 uint2 *r = runs2 + (size_t)t0 * nnzA + (valid ? e : a1 - 1);     // r[tt * nnzA].x = start of tile tt's part
                 int tcur = 1;
                 if (valid) {
@@ -1211,8 +1250,10 @@ __global__ __launch_bounds__(256) void smm_runs_slab(int nrows, int m, int n_sla
             for (int eb = a0; eb < a1; eb += WAVE) {
                 const int e = eb + lane;
                 if (e >= a1) continue;
-                const unsigned p0 = Ps[e];
-                const unsigned p1 = e + 1 < a1 ? Ps[e + 1] : total;
+                unsigned p0 = Ps[e];
+                unsigned p1 = e + 1 < a1 ? Ps[e + 1] : total;
+                p0 = p0 < total ? p0 : total;                   // (the same clamp as in the pass above)
+                p1 = p1 < p0 ? p0 : (p1 < total ? p1 : total);
                 unsigned base = dst0[e];
                 for (int sp = 0; sp < s; ++sp) base += cnt_of(sp, e);
                 uint2 *r = runs2 + (size_t)t0 * nnzA + e;
@@ -1270,6 +1311,7 @@ struct NumericArgs {
     // column slabs (smm_runs_slab): slab-local lists, ub_off indexed [slab * mtot + row]
     const uint2 *runs2; int n_slabs, tps, ws, mtot; int64_t nnzA;
     unsigned long long *stamps;     // diagnostic builds (-DSMM_STAMPS) only: 4 phase totals
+    unsigned *err;                  // the context's error word (PLAN_ERR_*)
     // dense output
     double *c_dense; int64_t ldc;
 };
@@ -1718,11 +1760,18 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
         const int ashift = cshift - lo_c;                    // slab-local column -> accumulator of this tile
         int *__restrict__ oi = A.c_idx + rs;
         double *__restrict__ ov = A.c_val + rs;
+        const unsigned rowlen = (unsigned)(A.c_ptr[row + 1] - rs);
         for (int rb = a0; rb < a1; rb += NW * WAVE) {
             const int e = rb + wave + NW * lane;
             const bool ev = e < a1;
             const uint2 d = rt[ev ? e : a1 - 1];
-            const unsigned src0 = d.x & 0xffffu, len = ev ? d.x >> 16 : 0u, dst0 = d.y;
+            const unsigned src0 = d.x & 0xffffu, dst0 = d.y;
+            unsigned len = ev ? d.x >> 16 : 0u;
+            // (always on: a sub-run must lie inside the row of C and inside one tile; a table that says otherwise costs
+            // this row its entries, never a store outside it -- the list side is covered by the slack behind the lists)
+#if SMM_CLAMPS
+            if (len > (unsigned)A.wc || dst0 > rowlen || len > rowlen - dst0) { plan_err(A.err, PLAN_ERR_RUNS2, row); len = 0u; }
+#endif
             const int nch = (int)((len + WAVE - 1) >> 6);
             const int incl = wave_scan_incl(nch);
             const int total = rl(incl, WAVE - 1);
@@ -1759,14 +1808,28 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
         int *__restrict__ oi = A.c_idx + rs;
         double *__restrict__ ov = A.c_val + rs;
         const size_t per = (size_t)A.nct + 1;
+        const unsigned rowlen = (unsigned)(A.c_ptr[row + 1] - rs);
         const int2 tl = A.tail[row];
-        const int e0 = tl.x;
+        int e0 = tl.x;
+        unsigned tail0 = (unsigned)tl.y;
+        // (always on: the tail descriptor and the sub-run bounds are smm_runs' output.  Out of range they would make
+        // r1 - r0 wrap to 2^26 chunks -- a hang -- or place stores past the row: clamped, and recorded)
+#if SMM_CLAMPS
+        if (e0 < a0 || e0 > a1 || tail0 > rowlen) {
+            if (threadIdx.x == 0) plan_err(A.err, PLAN_ERR_TAIL, row);
+            e0 = e0 < a0 ? a0 : (e0 > a1 ? a1 : e0);
+            tail0 = rowlen;
+        }
+#endif
         for (int rb = a0; rb < e0; rb += NW * WAVE) {
             const int e = rb + wave + NW * lane;
             const bool ev = e < e0;
             const unsigned *rp = A.runs + (size_t)(ev ? e : e0 - 1) * per + tc;
             const unsigned r0 = rp[0];
-            const unsigned r1 = ev ? rp[1] : r0;
+            unsigned r1 = ev ? rp[1] : r0;
+#if SMM_CLAMPS
+            if (r1 < r0 || r1 > rowlen) { plan_err(A.err, PLAN_ERR_RUNS, row); r1 = r0; }
+#endif
             const int nch = (int)((r1 - r0 + WAVE - 1) >> 6);
             const int incl = wave_scan_incl(nch);
             const int total = rl(incl, WAVE - 1);
@@ -1792,7 +1855,6 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
         }
         // the tail (see TAIL_MIN): list positions [tl.y, row length) 64 at a time, this tile's columns kept.
         // (the dummy word of idle lanes, -1 or 0xffff, lies in no tile: B has < 65 535 columns when lists are 16-bit)
-        const unsigned rowlen = (unsigned)(A.c_ptr[row + 1] - rs), tail0 = (unsigned)tl.y;
         const unsigned ntc = rowlen > tail0 ? (rowlen - tail0 + WAVE - 1) >> 6 : 0u;
         for (unsigned q0 = (unsigned)wave; q0 < ntc; q0 += NW * EPI_UNROLL) {
             int c[EPI_UNROLL];
@@ -1875,6 +1937,7 @@ struct HashArgs {
     const int64_t *c_ptr; int *c_idx; double *c_val;
     const int64_t *ub_off; const void *tmp_idx; int list16;
     const int *dummy_idx; const double *dummy_val;
+    unsigned *err;                  // the context's error word (PLAN_ERR_*)
 };
 
 constexpr int HASH_UNROLL = 8;
@@ -1908,15 +1971,18 @@ __global__ __launch_bounds__(NW * TPB * 64) void smm_numeric_hash(const HashArgs
         const int64_t lbase = have ? A.ub_off[row] : 0;
         // 1. empty table, accumulators at -0.0 (additive identity: reproduces `values[i] = p`)
         for (int h = tlane; h < HSIZE; h += TN) keys[h] = -1;
-        for (int s = tlane; s < cnt; s += TN) vals[s] = -0.0;
+        for (int s = tlane; s < cnt && s < NVAL; s += TN) vals[s] = -0.0;
         team_sync();
         // 2. insert the row's columns: slot = position in the first-touch list
-        for (int s = tlane; s < cnt; s += TN) {
+        // (always on: every probe sequence is bounded by the table size -- a row count beyond the bin's limit, or a
+        // product whose column the symbolic phase did not list, is recorded instead of spinning for ever)
+        for (int s = tlane; s < cnt && s < NVAL; s += TN) {
             const int c = list_at(A.tmp_idx, lbase + s, l16);
-            int h = hash(c);
-            while (atomicCAS(&keys[h], -1, c) != -1) h = (h + 1) & (HSIZE - 1);
-            slots[h] = (unsigned short)s;
+            int h = hash(c), tries = 0;
+            while (atomicCAS(&keys[h], -1, c) != -1 && ++tries < HSIZE) h = (h + 1) & (HSIZE - 1);
+            if (tries < HSIZE) slots[h] = (unsigned short)s;
         }
+        if (cnt > NVAL && tlane == 0) plan_err(A.err, PLAN_ERR_COUNT, row);
         team_sync();
         // 3. products: wave w of the team takes A's entries w, w+NW, ... (whole rows of B)
         if (have && cnt > 0) {
@@ -1972,9 +2038,10 @@ __global__ __launch_bounds__(NW * TPB * 64) void smm_numeric_hash(const HashArgs
 #pragma unroll
                     for (int u = 0; u < HASH_UNROLL; ++u) {
                         if (c[u] >= thresh) {                           // also drops the dummy -1
-                            int h = hash(c[u]);
-                            while (keys[h] != c[u]) h = (h + 1) & (HSIZE - 1);
-                            lds_add(&vals[slots[h]], a[u] * v[u]);
+                            int h = hash(c[u]), tries = 0;
+                            while (keys[h] != c[u] && ++tries < HSIZE) h = (h + 1) & (HSIZE - 1);
+                            if (tries < HSIZE) lds_add(&vals[slots[h]], a[u] * v[u]);
+                            else plan_err(A.err, PLAN_ERR_HASH, row);
                         }
                     }
                 }
@@ -1984,7 +2051,7 @@ __global__ __launch_bounds__(NW * TPB * 64) void smm_numeric_hash(const HashArgs
         }
         team_sync();
         // 4. the row, in first-touch order
-        for (int s = tlane; s < cnt; s += TN) {
+        for (int s = tlane; s < cnt && s < NVAL; s += TN) {
             A.c_idx[rs + s] = list_at(A.tmp_idx, lbase + s, l16);
             A.c_val[rs + s] = vals[s];
         }
@@ -2610,6 +2677,151 @@ __global__ __launch_bounds__(256) void smm_mirror_sort(int n, const int64_t *__r
             for (int x = threadIdx.x; x < len; x += blockDim.x) { fidx[b + x] = srt_key[x]; fval[b + x] = srt_val[x]; }
             __syncthreads();
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Plan checker (SMM_CHECK=1 / smm_ctx_set_check / smm_plan_check; every test runs with it).  It verifies, row by
+// row, every invariant the numeric phase relies on, and records violations as PLAN_ERR_* bits:
+//   capacities   ub_off non-decreasing (a negative capacity makes two lists overlap), list length <= capacity
+//   counts       c_ptr[row+1] - c_ptr[row] == list length (slabs: the sum over the row's slab lists)
+//   start slots  P[a0] == 0, P[e] <= P[e+1] <= list length
+//   lists        every entry is a column of the result (of the slab)
+//   sub-runs     runs[e][0] == P[e], runs[e][nct] == P[e+1], non-decreasing in between, and every list entry of
+//                sub-run (e, t) is a column of tile t; tail = {e0 in [a0, a1], P[e0]}
+//   slab table   runs2[t][e]: source inside [P_s[e], P_s[e+1]), destination + length inside the row, columns of
+//                tile t only, and the lengths of a row add up to the row
+// One wave per row; `units` = 1 list per row, or n_slabs (list s of row r at index s * m + r).
+template <typename LT>
+__global__ __launch_bounds__(256) void smm_plan_check_rows(int m, int n_slabs, int ws, int ncols, int64_t nnzA, int64_t total_cap,
+                                                           const int *__restrict__ a_ptr, const int64_t *__restrict__ ub_off,
+                                                           const int *__restrict__ cnt, const int *__restrict__ rowcnt,
+                                                           const int64_t *__restrict__ c_ptr, const unsigned *__restrict__ P,
+                                                           const LT *__restrict__ tmp, unsigned *__restrict__ err)
+{
+    const int lane = lane_id();
+    const int wpb = blockDim.x / WAVE;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (c_ptr[0] != 0 || ub_off[0] != 0 || ub_off[(size_t)n_slabs * m] != total_cap) plan_err(err, PLAN_ERR_CAP, 0);
+    }
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < m; row += gridDim.x * wpb) {
+        const int a0 = a_ptr[row], a1 = a_ptr[row + 1];
+        int64_t rowtot = 0;
+        unsigned bad = 0;
+        for (int s = 0; s < n_slabs; ++s) {
+            const size_t u = (size_t)s * m + row;
+            const int64_t lo = ub_off[u], cap = ub_off[u + 1] - lo;
+            const int n = cnt[u];
+            if (cap < 0 || lo < 0 || lo > total_cap) { bad |= PLAN_ERR_CAP; continue; }
+            if (n < 0 || n > cap) { bad |= PLAN_ERR_CAP; continue; }
+            rowtot += n;
+            const int64_t slab_lo = (int64_t)s * ws;
+            const int64_t width = n_slabs > 1 ? ((ncols - slab_lo) < ws ? (ncols - slab_lo) : ws) : ncols;
+            for (int i = lane; i < n; i += WAVE)
+                if ((int64_t)tmp[lo + i] < 0 || (int64_t)tmp[lo + i] >= width) bad |= PLAN_ERR_LIST;
+            if (n > 0 || n_slabs > 1) {                // (rows no symbolic kernel visited -- no products -- have no start slots)
+                const unsigned *Ps = P + (size_t)s * nnzA;
+                for (int e = a0 + lane; e < a1; e += WAVE) {
+                    const unsigned q0 = Ps[e], q1 = e + 1 < a1 ? Ps[e + 1] : (unsigned)n;
+                    if (q0 > q1 || q1 > (unsigned)n || (e == a0 && q0 != 0u)) bad |= PLAN_ERR_P;
+                }
+            }
+        }
+        if (rowcnt[row] != rowtot || c_ptr[row + 1] - c_ptr[row] != rowtot) bad |= PLAN_ERR_COUNT;
+        if (bad) plan_err(err, bad, row);
+    }
+}
+
+template <typename LT>
+__global__ __launch_bounds__(256) void smm_plan_check_runs(int nrows, int nct, int wc, const int *__restrict__ rowlist,
+                                                           const int *__restrict__ a_ptr, const int64_t *__restrict__ ub_off,
+                                                           const int *__restrict__ rowcnt, const unsigned *__restrict__ P,
+                                                           const LT *__restrict__ tmp, const unsigned *__restrict__ runs,
+                                                           const int2 *__restrict__ tail, unsigned *__restrict__ err)
+{
+    const int lane = lane_id();
+    const int wpb = blockDim.x / WAVE;
+    for (int ri = blockIdx.x * wpb + (threadIdx.x >> 6); ri < nrows; ri += gridDim.x * wpb) {
+        const int row = rowlist ? rowlist[ri] : ri;
+        const int a0 = a_ptr[row], a1 = a_ptr[row + 1];
+        const unsigned total = (unsigned)rowcnt[row];
+        const LT *__restrict__ list = tmp + ub_off[row];
+        const int2 tl = tail[row];
+        unsigned bad = 0;
+        if (tl.x < a0 || tl.x > a1 || (unsigned)tl.y != (tl.x < a1 ? P[tl.x < a0 ? a0 : tl.x] : total)) bad |= PLAN_ERR_TAIL;
+        const int e0 = tl.x < a0 ? a0 : (tl.x > a1 ? a1 : tl.x);
+        for (int e = a0; e < e0; ++e) {                         // one step at a time, its sub-runs spread over the lanes
+            const unsigned *r = runs + (size_t)e * (nct + 1);
+            const unsigned q0 = P[e], q1 = e + 1 < a1 ? P[e + 1] : total;
+            if (r[0] != q0 || r[nct] != q1) bad |= PLAN_ERR_RUNS;
+            if (q0 > q1 || q1 > total) { bad |= PLAN_ERR_P; continue; }
+            for (int t = 0; t < nct; ++t) {
+                const unsigned s0 = r[t], s1 = r[t + 1];
+                if (s0 > s1 || s0 < q0 || s1 > q1) { bad |= PLAN_ERR_RUNS; continue; }
+                for (unsigned i = s0 + lane; i < s1; i += WAVE)
+                    if ((int)list[i] / wc != t) bad |= PLAN_ERR_LIST;
+            }
+        }
+        if (bad) plan_err(err, bad, row);
+    }
+}
+
+__global__ __launch_bounds__(256) void smm_plan_check_runs2(int nrows, int m, int n_slabs, int tps, int nct, int wc, int64_t nnzA,
+                                                            const int *__restrict__ rowlist, const int *__restrict__ a_ptr,
+                                                            const int64_t *__restrict__ ub_off, const int *__restrict__ scnt,
+                                                            const int64_t *__restrict__ c_ptr, const unsigned *__restrict__ P,
+                                                            const unsigned short *__restrict__ tmp, const uint2 *__restrict__ runs2,
+                                                            unsigned *__restrict__ err)
+{
+    const int lane = lane_id();
+    const int wpb = blockDim.x / WAVE;
+    for (int ri = blockIdx.x * wpb + (threadIdx.x >> 6); ri < nrows; ri += gridDim.x * wpb) {
+        const int row = rowlist ? rowlist[ri] : ri;
+        const int a0 = a_ptr[row], a1 = a_ptr[row + 1];
+        const unsigned rowlen = (unsigned)(c_ptr[row + 1] - c_ptr[row]);
+        unsigned bad = 0;
+        unsigned long long covered = 0;
+        for (int t = 0; t < nct; ++t) {
+            const int s = t / tps, tl = t - s * tps;
+            const unsigned total = (unsigned)scnt[(size_t)s * m + row];
+            const unsigned short *__restrict__ list = tmp + ub_off[(size_t)s * m + row];
+            const unsigned *Ps = P + (size_t)s * nnzA;
+            for (int e = a0; e < a1; ++e) {
+                const uint2 d = runs2[(size_t)t * nnzA + e];
+                const unsigned src = d.x & 0xffffu, len = d.x >> 16, dst = d.y;
+                const unsigned q0 = Ps[e], q1 = e + 1 < a1 ? Ps[e + 1] : total;
+                if (q0 > q1 || q1 > total) { bad |= PLAN_ERR_P; continue; }
+                if (src < q0 || src + len > q1 || dst > rowlen || len > rowlen - dst) { bad |= PLAN_ERR_RUNS2; continue; }
+                covered += len;
+                for (unsigned i = src + lane; i < src + len; i += WAVE)
+                    if ((int)list[i] / wc != tl) bad |= PLAN_ERR_LIST;
+            }
+        }
+        if (covered != rowlen) bad |= PLAN_ERR_RUNS2;
+        if (bad) plan_err(err, bad, row);
+    }
+}
+
+// Test hook (smm_plan_inject_fault): damage ONE piece of a plan's metadata the way a defect in the kernel that
+// produces it would -- so that the tests can assert the consumer reports it instead of hanging or faulting.
+//   1 a sub-run that ends before it starts     2 a sub-run bound beyond the row      3 a tail descriptor outside the row
+//   4 a row count that disagrees with c_ptr    5 a list entry that is no column      6 a slab sub-run with absurd length / target
+//   7 a start slot beyond the list             8 a negative list capacity
+__global__ void smm_plan_corrupt(int kind, int row, int nct, int64_t nnzA, const int *__restrict__ a_ptr, int64_t *__restrict__ ub_off,
+                                 int *__restrict__ rowcnt, unsigned *__restrict__ P, void *__restrict__ tmp, int list16,
+                                 unsigned *__restrict__ runs, int2 *__restrict__ tail, uint2 *__restrict__ runs2)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    const int a0 = a_ptr[row], a1 = a_ptr[row + 1];
+    switch (kind) {
+    case 1: if (runs) { unsigned *r = runs + (size_t)a0 * (nct + 1); const unsigned x = r[0]; r[0] = r[nct] + 7u; r[nct] = x; } break;
+    case 2: if (runs) runs[(size_t)a0 * (nct + 1) + nct] = 0x7ffffff0u; break;
+    case 3: if (tail) tail[row] = make_int2(a1 + 5, 0x0ffffff0); break;
+    case 4: rowcnt[row] += 1; break;
+    case 5: if (list16) ((unsigned short *)tmp)[ub_off[row]] = 0xfffeu; else ((int *)tmp)[ub_off[row]] = 0x7ffffff0; break;
+    case 6: if (runs2) runs2[a0] = make_uint2(0xffff0000u, 0xfffffff0u); break;
+    case 7: P[a0 + (a1 - a0 > 1 ? 1 : 0)] = 0xfffffff0u; break;
+    case 8: ub_off[row + 1] = ub_off[row] - 1; break;
     }
 }
 

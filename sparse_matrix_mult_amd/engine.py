@@ -91,6 +91,11 @@ class Context:
         ds_add_f64 in ascending lane order.  inject_fault=True exercises that failure path."""
         check(self.lib, self.lib.smm_ctx_exact_selftest(self.handle, 1 if inject_fault else 0))
 
+    def set_check(self, enable=True):
+        """Run the plan checker at the end of every symbolic phase (also env SMM_CHECK=1): inconsistent plan
+        metadata raises SmmError (SMM_ERR_INTERNAL).  The kernels' own bounds clamps are always on."""
+        check(self.lib, self.lib.smm_ctx_set_check(self.handle, 1 if enable else 0))
+
     def timing(self, enable=True):
         check(self.lib, self.lib.smm_ctx_timing(self.handle, 1 if enable else 0))
 
@@ -289,6 +294,14 @@ class Plan:
 
     def device_bytes(self):
         return int(self.ctx.lib.smm_plan_device_bytes(self.handle)) if self.handle else 0
+
+    def check(self):
+        """Verify the plan's metadata on the device (smm_plan_check); raises SmmError (SMM_ERR_INTERNAL)."""
+        check(self.ctx.lib, self.ctx.lib.smm_plan_check(self.ctx.handle, self.handle))
+
+    def inject_fault(self, kind):
+        """TEST HOOK: damage one piece of the plan's metadata (smm_plan_inject_fault)."""
+        check(self.ctx.lib, self.ctx.lib.smm_plan_inject_fault(self.ctx.handle, self.handle, int(kind)))
 
     def numeric_host(self, index_dtype=None):
         """Run the numeric phase of this plan (again, after update_values on its operands if wanted) and return

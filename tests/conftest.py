@@ -4,6 +4,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# every context of the test-suite verifies every plan it makes (smm_plan_check; tests/test_gpu_plan_check.py)
+os.environ.setdefault("SMM_CHECK", "1")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
