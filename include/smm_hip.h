@@ -207,9 +207,10 @@ void smm_plan_destroy(smm_plan *plan);
  * symmetric matrix, in HBM: _symbolic writes the full row pointer (n+1 entries) and returns the full nnz, the
  * caller allocates, _fill writes indices and values.  Order inside row i of the full matrix: first the mirrored
  * entries (columns j < i) in ascending column order, then the row's own entries in the order the input holds them
- * (the reference's first-touch order).  A row may receive at most 8192 mirrored entries (they are sorted in
- * LDS); fuller results are refused with SMM_ERR_INVALID: there, symmetric=False is the cheaper way to the full
- * matrix.  Entries left of the diagonal in the input are refused as well. */
+ * (the reference's first-touch order).  Any row length: mirrored segments of up to 8192 entries are sorted in LDS,
+ * longer ones (results as full as the BASELINE configs') are placed by rank -- the columns of a segment are distinct,
+ * so an entry's sorted position is the number of set bits below its column in a bitmap of the segment.  Entries left
+ * of the diagonal in the input are refused with SMM_ERR_INVALID. */
 int  smm_csr_mirror_symbolic(smm_ctx *ctx, int64_t n, const int64_t *d_indptr, const int32_t *d_indices,
                              int64_t *d_full_indptr, int64_t *nnz_full);
 int  smm_csr_mirror_fill(smm_ctx *ctx, int64_t n, const int64_t *d_indptr, const int32_t *d_indices, const double *d_data,

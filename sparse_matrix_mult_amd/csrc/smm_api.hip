@@ -2109,9 +2109,7 @@ extern "C" int smm_csr_mirror_symbolic(smm_ctx *c, int64_t n, const int64_t *d_i
     pool_free(c, mcnt); pool_free(c, flen);
     if (rc != SMM_OK) return rc;
     if (bad) return fail(SMM_ERR_INVALID, "CSR mirror: the input holds entries left of the diagonal or outside the n x n square");
-    if (maxseg > MIRROR_MAX_SEG)
-        return fail(SMM_ERR_INVALID, "CSR mirror: a row would receive %d mirrored entries (limit %d); for results this full compute the "
-                                     "product with symmetric=False instead", maxseg, MIRROR_MAX_SEG);
+    (void)maxseg;                 // (any length: segments beyond the LDS sort are placed by rank, smm_mirror_rank)
     return SMM_OK;
 }
 
@@ -2132,8 +2130,35 @@ extern "C" int smm_csr_mirror_fill(smm_ctx *c, int64_t n, const int64_t *d_indpt
     if (e == hipSuccess) e = hipMemsetAsync(c->d_flags, 0, sizeof(unsigned), c->stream);
     const int grid = (int)std::min<int64_t>((n + 3) / 4, 16384);
     LAUNCH(c, "smm_mirror_count", smm_mirror_count, grid, 256, 0, (int)n, d_indptr, d_indices, mcnt, c->d_flags);
+    // rows that receive more mirrored entries than the LDS sort holds: their entries are staged and placed by rank
+    int64_t *big = nullptr, *toff = nullptr; int *tidx = nullptr; double *tval = nullptr;
+    int64_t total_big = 0;
+    auto drop = [&]() { pool_free(c, mcnt); pool_free(c, cursor); pool_free(c, big); pool_free(c, toff); pool_free(c, tidx); pool_free(c, tval); };
+    rc = pool_get(c, (size_t)n, &big);
+    if (rc == SMM_OK) rc = pool_get(c, (size_t)n + 1, &toff);
+    if (rc == SMM_OK) {
+        LAUNCH(c, "smm_mirror_big", smm_mirror_big, std::min<int64_t>((n + 255) / 256, 4096), 256, 0, (int)n, (const int *)mcnt, big);
+        rc = scan_launch<int64_t>(c, n, big, toff);
+    }
+    if (rc == SMM_OK) {
+        if (e == hipSuccess) e = hipMemcpyAsync(&total_big, toff + n, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(SMM_ERR_HIP, "CSR mirror: %s", hipGetErrorString(e));
+    }
+    if (rc == SMM_OK && total_big > 0) {
+        rc = pool_get(c, (size_t)total_big, &tidx);
+        if (rc == SMM_OK) rc = pool_get(c, (size_t)total_big, &tval);
+    }
+    if (rc != SMM_OK) { drop(); return rc; }
     LAUNCH(c, "smm_mirror_fill", smm_mirror_fill, grid, 256, 0, (int)n, d_indptr, d_indices, d_data, d_full_indptr, (const int *)mcnt, cursor,
-           d_full_indices, d_full_data);
+           d_full_indices, d_full_data, total_big > 0 ? (const int64_t *)toff : (const int64_t *)nullptr, tidx, tval);
+    if (total_big > 0) {
+        auto rk = smm_mirror_rank;
+        const size_t rlds = (size_t)2 * RANK_WORDS * sizeof(unsigned);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds);
+        LAUNCH(c, "smm_mirror_rank", rk, std::min<int64_t>(n, (int64_t)c->n_cu * 4), 1024, rlds, (int)n, d_full_indptr, (const int *)mcnt,
+               (const int64_t *)toff, (const int *)tidx, (const double *)tval, d_full_indices, d_full_data);
+    }
     LAUNCH(c, "smm_mirror_sort", smm_mirror_sort<false>, grid, 256, 0, (int)n, d_full_indptr, (const int *)mcnt, d_full_indices, d_full_data);
     {
         auto kern = smm_mirror_sort<true>;
@@ -2143,8 +2168,8 @@ extern "C" int smm_csr_mirror_fill(smm_ctx *c, int64_t n, const int64_t *d_indpt
                d_full_indices, d_full_data);
     }
     if (e == hipSuccess) e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);     // mcnt / cursor return to the pool
-    pool_free(c, mcnt); pool_free(c, cursor);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);     // mcnt / cursor / the staging array return to the pool
+    drop();
     if (e != hipSuccess) return fail(SMM_ERR_HIP, "CSR mirror: %s", hipGetErrorString(e));
     return SMM_OK;
 }

@@ -2565,8 +2565,8 @@ __global__ __launch_bounds__(256) void smm_mirror_upper(int n, double *__restric
 // Three steps: count (one atomic per strictly-upper entry on its target row), fill (own entries copied behind
 // the space of the mirrored ones, mirrored ones dropped into it through a per-row cursor: arrival order), and a
 // sort of each row's mirrored segment by column, which makes the result deterministic.  The sort runs in LDS
-// (one wave per row up to 64 mirrored entries, one workgroup up to MIRROR_MAX_SEG); longer segments are refused:
-// for results that full a recomputation with symmetric=False is cheaper than any transposition.
+// (one wave per row up to 64 mirrored entries, one workgroup up to MIRROR_MAX_SEG); longer segments -- results as full
+// as the BASELINE configs' -- are staged and placed by RANK instead (smm_mirror_rank below): no limit on a row.
 constexpr int MIRROR_MAX_SEG = 8192;
 
 __global__ __launch_bounds__(256) void smm_mirror_count(int n, const int64_t *__restrict__ uptr, const int *__restrict__ uidx,
@@ -2596,10 +2596,19 @@ __global__ __launch_bounds__(256) void smm_mirror_rowlen(int n, const int64_t *_
     for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
     if (lane_id() == 0 && mx > 0) atomicMax(maxseg, mx);
 }
+// big[i] = mirrored entries of row i when they are too many for the LDS sort (they travel through a staging array and
+// are RANKED instead: smm_mirror_rank), else 0
+__global__ __launch_bounds__(256) void smm_mirror_big(int n, const int *__restrict__ mcnt, int64_t *__restrict__ big)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        big[i] = mcnt[i] > MIRROR_MAX_SEG ? (int64_t)mcnt[i] : 0;
+}
+// toff / tidx / tval: staging array of the long segments (toff = exclusive scan of big[]; NULL when there is none)
 __global__ __launch_bounds__(256) void smm_mirror_fill(int n, const int64_t *__restrict__ uptr, const int *__restrict__ uidx,
                                                        const double *__restrict__ uval, const int64_t *__restrict__ fptr,
                                                        const int *__restrict__ mcnt, int *__restrict__ cursor,
-                                                       int *__restrict__ fidx, double *__restrict__ fval)
+                                                       int *__restrict__ fidx, double *__restrict__ fval,
+                                                       const int64_t *__restrict__ toff, int *__restrict__ tidx, double *__restrict__ tval)
 {
     const int lane = lane_id();
     const int wpb = blockDim.x / WAVE;
@@ -2611,10 +2620,77 @@ __global__ __launch_bounds__(256) void smm_mirror_fill(int n, const int64_t *__r
             fidx[own + (k - s)] = j;
             fval[own + (k - s)] = v;
             if (j > i) {
-                const int64_t at = fptr[j] + atomicAdd(&cursor[j], 1);
-                fidx[at] = i;
-                fval[at] = v;
+                const int slot = atomicAdd(&cursor[j], 1);
+                if (toff && mcnt[j] > MIRROR_MAX_SEG) {
+                    const int64_t at = toff[j] + slot;
+                    tidx[at] = i; tval[at] = v;
+                } else {
+                    const int64_t at = fptr[j] + slot;
+                    fidx[at] = i; fval[at] = v;
+                }
             }
+        }
+    }
+}
+// Mirrored segments longer than MIRROR_MAX_SEG (results as full as the BASELINE configs': a row receives up to n
+// entries): no comparison sort.  The columns of a segment are DISTINCT integers below i, so the sorted position of an
+// entry is its column's rank in the segment = the number of set bits below it in a bitmap of the segment's columns.
+// One workgroup per row: bitmap of a range of RANK_WORDS * 32 columns in LDS (atomic OR), per-word exclusive prefix of
+// the popcounts (block scan), then every staged entry goes to fptr[i] + (entries below the range) + rank.  Rows wider
+// than one range take one pass per range.  Linear in the segment, deterministic, any length.
+constexpr int RANK_WORDS = 16384;                 // 64 KB of bitmap + 64 KB of prefixes: 524 288 columns per pass
+__global__ __launch_bounds__(1024) void smm_mirror_rank(int n, const int64_t *__restrict__ fptr, const int *__restrict__ mcnt,
+                                                        const int64_t *__restrict__ toff, const int *__restrict__ tidx,
+                                                        const double *__restrict__ tval, int *__restrict__ fidx, double *__restrict__ fval)
+{
+    extern __shared__ unsigned rk_lds[];
+    unsigned *bm = rk_lds, *pre = rk_lds + RANK_WORDS;
+    __shared__ unsigned wsum[16];
+    __shared__ unsigned below_s;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int len = mcnt[i];                                       // workgroup-uniform
+        if (len <= MIRROR_MAX_SEG) continue;
+        const int *__restrict__ tk = tidx + toff[i];
+        const double *__restrict__ tv = tval + toff[i];
+        const int64_t dst = fptr[i];
+        for (int lo = 0; lo < i; lo += RANK_WORDS * 32) {
+            const int span = (i - lo) < RANK_WORDS * 32 ? (i - lo) : RANK_WORDS * 32;     // columns lo .. lo + span - 1
+            const int words = (span + 31) >> 5;
+            for (int w = threadIdx.x; w < words; w += blockDim.x) bm[w] = 0u;
+            if (threadIdx.x == 0) below_s = 0u;
+            __syncthreads();
+            unsigned below = 0;
+            for (int x = threadIdx.x; x < len; x += blockDim.x) {
+                const int c = tk[x] - lo;
+                if (c < 0) ++below;
+                else if (c < span) atomicOr(&bm[c >> 5], 1u << (c & 31));
+            }
+            for (int o = 32; o > 0; o >>= 1) below += __shfl_down(below, o);
+            if (lane == 0 && below) atomicAdd(&below_s, below);
+            __syncthreads();
+            // exclusive prefix of the words' popcounts: thread t owns the words [t * per, (t + 1) * per)
+            const int per = (words + (int)blockDim.x - 1) / (int)blockDim.x;
+            const int w0 = threadIdx.x * per, w1 = (w0 + per) < words ? (w0 + per) : words;
+            unsigned mine = 0;
+            for (int w = w0; w < w1; ++w) mine += (unsigned)__popc(bm[w]);
+            unsigned incl = mine;
+            for (int o = 1; o < WAVE; o <<= 1) { const unsigned y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+            if (lane == WAVE - 1) wsum[wave] = incl;
+            __syncthreads();
+            unsigned run = incl - mine + below_s;
+            for (int w = 0; w < wave; ++w) run += wsum[w];
+            for (int w = w0; w < w1; ++w) { pre[w] = run; run += (unsigned)__popc(bm[w]); }
+            __syncthreads();
+            for (int x = threadIdx.x; x < len; x += blockDim.x) {
+                const int col = tk[x], c = col - lo;
+                if (c >= 0 && c < span) {
+                    const unsigned r = pre[c >> 5] + (unsigned)__popc(bm[c >> 5] & ((1u << (c & 31)) - 1u));
+                    fidx[dst + r] = col;
+                    fval[dst + r] = tv[x];
+                }
+            }
+            __syncthreads();
         }
     }
 }

@@ -187,7 +187,8 @@ class Context:
     def spgemm_host_mirrored(self, a, b, exact=False):
         """The symmetric product's upper triangle (symmetric=True), mirrored on the device to the full symmetric
         CSR (smm_csr_mirror_*).  Row i: mirrored entries (columns < i) in ascending column order, then the row's
-        own entries in first-touch order.  (indptr int64, indices int32, data float64) numpy arrays."""
+        own entries in first-touch order; any row length (long segments are placed by rank on the device).
+        (indptr int64, indices int32 -- int64 when nnz >= 2^31 --, data float64) numpy arrays."""
         if a.rows != b.cols:
             raise ValueError("For symmetric output, the resulting matrix must be square.")
         n = a.rows
@@ -200,8 +201,6 @@ class Context:
             fp = self._dmalloc(8 * (n + 1)); bufs.append(fp)
             nnz = ctypes.c_int64()
             check(self.lib, self.lib.smm_csr_mirror_symbolic(self.handle, n, up, ui, fp, ctypes.byref(nnz)))
-            if nnz.value > np.iinfo(np.int32).max:
-                raise SmmError(-5, "mirrored result has more than 2^31 nonzeros")
             fi, fv = self._dmalloc(4 * max(nnz.value, 1)), self._dmalloc(8 * max(nnz.value, 1))
             bufs += [fi, fv]
             check(self.lib, self.lib.smm_csr_mirror_fill(self.handle, n, up, ui, uv, fp, fi, fv))
@@ -210,6 +209,8 @@ class Context:
             data = np.empty(nnz.value, dtype=np.float64)
             for dst, src in ((indptr, fp), (indices, fi), (data, fv)):
                 check(self.lib, self.lib.smm_memcpy_d2h(self.handle, _ptr(dst), src, dst.nbytes))
+            if nnz.value > np.iinfo(np.int32).max:            # scipy wants one index dtype per matrix (as spgemm_host)
+                indices = indices.astype(np.int64)
             return indptr, indices, data
         finally:
             plan.close()

@@ -40,8 +40,8 @@ _exact = os.environ.get("SMM_EXACT", "0") not in ("", "0")
 # product.  The default stays the reference's behaviour (lower triangle 0.0), and compute_full_matrix=1
 # keeps reproducing the reference exactly (off-diagonal doubled).  CSR results (output_format='sparse',
 # symmetric=True) are mirrored too: row i of the full matrix holds the mirrored entries (columns < i) in ascending
-# column order, then the reference's upper-triangle row in its first-touch order; a row may receive at most 8192
-# mirrored entries (sorted in LDS) -- fuller results raise, there symmetric=False is the cheaper full matrix.
+# column order, then the reference's upper-triangle row in its first-touch order; any row length (segments of up to
+# 8192 mirrored entries are sorted in LDS, longer ones placed by rank).
 _full_symmetric = False
 
 
