@@ -153,6 +153,16 @@ def run_config(cfg, args, env, steps, warmup, cpu_leg):
         r0, r1 = smm_dist.triple_row_shards(n, world)[rank] if rank < n else (n, n)
         out_buf = torch.empty((r1 - r0, n), dtype=torch.float64, device=device)
         a_t = b_t = None
+    elif cfg == "c1s":
+        # BASELINE configs[1] on the north star's LITERAL operands (SURVEY 8d "Synthetic inputs"): generated on the host by
+        # scipy (outside the timed region), uploaded once, resident in HBM before the first step
+        import scipy.sparse as sp
+        m = n = 50000
+        d = 0.01
+        mats = [sp.random(n, n, density=d, format="csr", random_state=np.random.default_rng(seed), dtype=np.float64) for seed in (1, 2)]
+        A, B = (ctx.csr_from_scipy(x) for x in mats)
+        del mats
+        a_t = b_t = out_buf = None
     else:
         if args.gather and not (args.rows or args.cols or args.density):
             n, d = 200000, 0.001
@@ -228,6 +238,34 @@ def run_config(cfg, args, env, steps, warmup, cpu_leg):
     ctx.timing(False)
     gather_ms = sum(a.elapsed_time(b) for a, b in gather_ev) / max(len(gather_ev), 1) if gather_ev else None
 
+    # --verify (N > 1, CSR configs): one more, untimed step; rank 0 then multiplies the row-wise concatenation of every
+    # rank's block of A with B on its own GPU and compares -- the exchanged global row pointer always, and with --gather
+    # the gathered indices / values too: concatenation in rank order IS the single-device CSR
+    # (the reference's stitch invariant, src/sparse_sparse_sparse.cpp:269-291).
+    verify = None
+    if args.verify and world > 1 and cfg in ("c1", "c4"):
+        got = step()
+        torch.cuda.synchronize()
+        if rank == 0:
+            blocks = [gen_csr_device(torch, m, n, d, 1 + 1000 * r, device) for r in range(world)]
+            offs = [0]
+            for blk in blocks:
+                offs.append(offs[-1] + int(blk[1].numel()))
+            ptr = torch.cat([blocks[0][0][:1].to(torch.int64)] + [blk[0][1:].to(torch.int64) + offs[r] for r, blk in enumerate(blocks)])
+            whole = ctx.csr_from_torch(m * world, n, ptr.to(torch.int32), torch.cat([blk[1] for blk in blocks]),
+                                       torch.cat([blk[2] for blk in blocks]))
+            sp_, si_, sv_ = ctx.spgemm_torch(whole, B, exact=args.exact)
+            ctx.synchronize()
+            verify = {"global_indptr_equals_single_gpu": bool(torch.equal(got[0], sp_))}
+            if args.gather:
+                verify["gathered_indices_equal_single_gpu"] = bool(torch.equal(got[1], si_))
+                verify["gathered_values_equal_single_gpu"] = bool(torch.equal(got[2], sv_) if args.exact else
+                                                                  torch.allclose(got[2], sv_, rtol=1e-10, atol=0.0))
+            whole.close()
+            del blocks, ptr, sp_, si_, sv_
+        del got
+        fence()
+
     t = torch.tensor([elapsed, float(units)], dtype=torch.float64, device="cpu" if rehearsal else device)
     if world > 1:
         tmax = t.clone()
@@ -249,9 +287,11 @@ def run_config(cfg, args, env, steps, warmup, cpu_leg):
         }
         if gather_ms is not None:
             line["gather_ms" if args.gather else "exchange_ms"] = gather_ms      # the collective part of one step (rank 0)
+        if verify is not None:
+            line["verify"] = verify
         mode = "SMM_EXACT (values bit-identical to the CPU loop)" if args.exact else "default (indices bit-exact, values to rounding)"
         par = f"row-sharded x{world}" if world > 1 else "single GPU"
-        if cfg in ("c1", "c4"):
+        if cfg in ("c1", "c1s", "c4"):
             nnz_c = units
             # compulsory one-touch bytes of one product
             alg_bytes = (4 * (m + 1) + 12 * nnz_a) + (4 * (n + 1) + 12 * nnz_b) + (8 * (m + 1) + 12 * nnz_c)
@@ -274,7 +314,9 @@ def run_config(cfg, args, env, steps, warmup, cpu_leg):
             line.update({
                 "metric": "output nnz/sec, CSR x CSR -> CSR SpGEMM (first-touch order, float64)",
                 "value": total_units * steps / elapsed, "unit": "nnz/s",
-                "config": {"workload": f"{m}x{n} x {n}x{n} uniform random CSR d={d} -> CSR, per GPU "
+                "config": {"workload": (f"{m}x{n} x {n}x{n} scipy.sparse.random(d={d}, random_state=default_rng(1|2)) -> CSR "
+                                        f"(BASELINE configs[1], the north star's literal operands)") if cfg == "c1s" else
+                                       f"{m}x{n} x {n}x{n} uniform random CSR d={d} -> CSR, per GPU "
                                        f"(BASELINE configs[{1 if cfg == 'c1' else 4}]{', all-gatherv inside the step' if args.gather else ''})",
                            "nnz_a": nnz_a, "nnz_b": nnz_b, "nnz_c_per_gpu": nnz_c, "mode": mode, "parallelism": par},
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -285,8 +327,13 @@ def run_config(cfg, args, env, steps, warmup, cpu_leg):
                              "algorithmic_bytes": alg_bytes,
                              # rate at which the phase moves its measured HBM-side traffic (PMC bytes / live duration)
                              "traffic_rate_GBs": (traffic / (num_ms * 1e-3) / 1e9) if (traffic and num_ms > 0) else None,
-                             "whole_step_frac": alg_bytes / (step_ms[len(step_ms) // 2] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "symbolic_kernel_ms": per_launch("smm_symbolic")},
+                             "symbolic_kernel_ms": per_launch("smm_symbolic"),
+                             # the same bytes over the WHOLE step (symbolic + runs + scans + numeric; median step): what one
+                             # product achieves, next to `frac`, which prices the dominant kernel alone as the contract asks
+                             "whole_step": {"achieved": alg_bytes / (step_ms[len(step_ms) // 2] * 1e-3) / 1e9, "unit": "GB/s",
+                                            "frac": alg_bytes / (step_ms[len(step_ms) // 2] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            "ms": step_ms[len(step_ms) // 2]}},
+                "whole_step_frac": alg_bytes / (step_ms[len(step_ms) // 2] * 1e-3) / 1e9 / HBM_PEAK_GBS,
             })
             if keep_last:                                                 # the CPU leg runs at N = 1 only
                 line["cpu_baseline"] = cpu_baseline(torch, a_t, b_t, n, (out[0], out[1], out[2]))
@@ -318,6 +365,7 @@ def run_config(cfg, args, env, steps, warmup, cpu_leg):
                              "kernels_ms": {k: per_launch(k) for k in ktimes if per_launch(k) > 0}},
             })
     out = None
+    ctx.synchronize()            # (also reports what the kernels' bounds clamps recorded, if anything: SMM_ERR_INTERNAL)
     A.close(); B.close()
     del a_t, b_t, out_buf
     torch.cuda.empty_cache()
@@ -329,8 +377,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c1", choices=["c1", "c2", "c3", "c4"],
-                    help="BASELINE config: c1 50k^2 -> sparse (default, the bench line), c2 -> dense, c3 triple product, "
+    ap.add_argument("--config", default="c1", choices=["c1", "c1s", "c2", "c3", "c4"],
+                    help="BASELINE config: c1 50k^2 -> sparse (default, the bench line), c1s the same on the literal "
+                         "scipy.sparse.random operands (host-generated, uploaded), c2 -> dense, c3 triple product, "
                          "c4 one rank's share of 200k^2 per GPU")
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--cols", type=int, default=0)
@@ -345,6 +394,9 @@ def main():
     ap.add_argument("--hash", type=str, default="", help="small,medium thresholds of the LDS-hash kernels (0,0 = off)")
     ap.add_argument("--slab", type=str, default="", help="mode,ws,rows_per_wave of the row-block x column-slab kernels "
                                                          "(mode 0 auto / 1 off / 2 force; ws 0 = L2-sized)")
+    ap.add_argument("--verify", action="store_true",
+                    help="N > 1, CSR configs: after the timed region rank 0 recomputes the product of the concatenated row blocks on "
+                         "one GPU and compares it with what the ranks exchanged / gathered (small sizes: rehearsals, first contact)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true",
                     help="default run only: skip the short runs of the other BASELINE configs (extra_configs)")
@@ -407,13 +459,13 @@ def main():
                    not (args.rows or args.cols or args.density or args.lds_cols or args.waves or args.hash or args.slab))
     if default_run:
         extra = {}
-        for name, cfg in (("c2", "c2"), ("c3", "c3"), ("c4_share", "c4")):
+        for name, cfg in (("c1_scipy", "c1s"), ("c2", "c2"), ("c3", "c3"), ("c4_share", "c4")):
             t0 = time.perf_counter()
             try:
                 r = run_config(cfg, args, env, 3, 1, cpu_leg=False)
                 extra[name] = {"ms_per_step": r["ms_per_step"], "ms_per_step_best": r["ms_per_step_best"], "metric": r["metric"],
                                "value": r["value"], "unit": r["unit"], "workload": r["config"]["workload"],
-                               "roofline": {k: r["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernels_ms")},
+                               "roofline": {k: r["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernels_ms", "whole_step")},
                                "wall_s_incl_input_generation": time.perf_counter() - t0}
             except Exception as e:                           # the headline stands on its own
                 extra[name] = {"error": repr(e)}

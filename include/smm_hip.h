@@ -84,6 +84,16 @@ int  smm_ctx_synchronize(smm_ctx *ctx);
 /* 1: every smm_spgemm_symbolic ends with smm_plan_check (also: env SMM_CHECK=1 when the context is created).  Off by
  * default: the checker streams the ordered lists once more (~2 ms at 50k x 50k); the kernels' own clamps are always on. */
 int  smm_ctx_set_check(smm_ctx *ctx, int enable);
+/* The context keeps freed scratch (the lists and tables of destroyed plans, result staging) in a pool for reuse.
+ * smm_ctx_release_pool returns the pool's free blocks to the device (matrix_ops.clear_cache() calls it);
+ * smm_ctx_pool_bytes says how much is held.  Every allocation that fails flushes the pool and retries once by itself. */
+int     smm_ctx_release_pool(smm_ctx *ctx);
+int64_t smm_ctx_pool_bytes(smm_ctx *ctx);
+/* TEST HOOK: the nth device allocation from now fails -- its first attempt only (the library's own flush-and-retry
+ * must make the call succeed), or with hard != 0 both attempts (the call returns SMM_ERR_ALLOC).  smm_ctx_alloc_retries
+ * counts the allocations that needed the retry. */
+int     smm_ctx_inject_alloc_failure(smm_ctx *ctx, int nth, int hard);
+int64_t smm_ctx_alloc_retries(smm_ctx *ctx);
 /* Per-kernel timing with HIP events on the context's stream (bench.py's roofline leg).
  * enable=1 starts recording; smm_ctx_kernel_time returns the accumulated milliseconds and
  * launch count of the named kernel since the last reset (name as printed by rocprofv3,

@@ -6,8 +6,8 @@ The package holds only the hot path named in SURVEY.md section 8: the ctypes mir
 reference's Python API (matrix_ops.py), an object layer over the C ABI (engine.py), the
 row-sharded multi-GPU driver (distributed.py) and the HIP sources (csrc/).
 """
-from .matrix_ops import (PinnedOperand, clear_cache, pin_operand, set_exact, set_full_symmetric, set_operand_cache,
-                         sparse_matrix_multiply)
+from .matrix_ops import (DeviceCSRResult, PinnedOperand, clear_cache, pin_operand, set_exact, set_full_symmetric,
+                         set_operand_cache, set_result_device, sparse_matrix_multiply)
 
-__all__ = ['sparse_matrix_multiply', 'set_exact', 'set_full_symmetric', 'clear_cache', 'set_operand_cache', 'pin_operand',
-           'PinnedOperand']
+__all__ = ['sparse_matrix_multiply', 'set_exact', 'set_full_symmetric', 'set_result_device', 'clear_cache', 'set_operand_cache',
+           'pin_operand', 'PinnedOperand', 'DeviceCSRResult']

@@ -47,6 +47,10 @@ V2_PROTOTYPES = {
     "smm_ctx_exact_selftest": (ctypes.c_int, [_vp, ctypes.c_int]),
     "smm_ctx_tune_symbolic": (ctypes.c_int, [_vp, ctypes.c_int]),
     "smm_ctx_set_check": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "smm_ctx_release_pool": (ctypes.c_int, [_vp]),
+    "smm_ctx_pool_bytes": (_c_i64, [_vp]),
+    "smm_ctx_inject_alloc_failure": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    "smm_ctx_alloc_retries": (_c_i64, [_vp]),
     "smm_plan_check": (ctypes.c_int, [_vp, _vp]),
     "smm_plan_inject_fault": (ctypes.c_int, [_vp, _vp, ctypes.c_int]),
     "smm_csr_from_host": (ctypes.c_int, [_vp, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _pp]),

@@ -95,12 +95,40 @@ struct smm_ctx {
     hipEvent_t pin_ev[PIN_SLOTS] = {nullptr};
     int exact_checked = 0;           // SMM_EXACT guard (smm_ctx_exact_selftest): 0 not run yet, 1 passed, -1 failed
     int check = 0;                   // 1: every symbolic phase ends with the plan checker (env SMM_CHECK, smm_ctx_set_check)
+    int inject_alloc_nth = 0;        // test hook: the n-th dev_malloc from now fails (its first attempt, or both: _hard)
+    bool inject_alloc_hard = false;
+    int64_t alloc_retries = 0;       // allocations that needed the pool flushed
     unsigned *d_flags = nullptr;     // [0] validation flags; +64: int -1 and +128: double 0 read by idle lanes
     unsigned *d_err = nullptr;       // plan error word: [0] PLAN_ERR_* bits, [1] lowest row that tripped one (kernels' always-on clamps, plan checker)
     std::recursive_mutex mu;         // every entry point that touches the context takes it: calls from
                                      // several host threads on one context serialise (one stream anyway)
 };
 #define CTX_LOCK(c) std::lock_guard<std::recursive_mutex> ctx_lock_((c)->mu)
+
+// Return every free block of the context's pool to the device (blocks handed out stay).  hipFree waits for the
+// device, so work still queued on blocks that went back to the pool has finished by then.
+static void pool_flush(smm_ctx *c)
+{
+    for (auto &b : c->pool) (void)hipFree(b.p);
+    c->pool.clear();
+}
+// hipMalloc for everything that is not pooled (operands and their cached copies).  An allocation that fails is
+// retried once after the pool's free blocks -- the multi-GB lists of closed plans live there -- went back to the
+// device; a failure never leaves HIP's sticky last error behind (the next LAUNCH_CHECK would report it).
+// Test hook (smm_ctx_inject_alloc_failure): the n-th call from now fails its first attempt -- or both.
+static hipError_t dev_malloc(smm_ctx *c, void **p, size_t bytes)
+{
+    bool fail_first = false, fail_both = false;
+    if (c->inject_alloc_nth > 0 && --c->inject_alloc_nth == 0) { fail_first = true; fail_both = c->inject_alloc_hard; }
+    hipError_t e = fail_first ? hipErrorOutOfMemory : hipMalloc(p, bytes);
+    if (e == hipSuccess) return e;
+    (void)hipGetLastError();
+    pool_flush(c);
+    ++c->alloc_retries;
+    e = fail_both ? hipErrorOutOfMemory : hipMalloc(p, bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); *p = nullptr; }
+    return e;
+}
 
 static int pool_alloc(smm_ctx *c, size_t bytes, void **out)
 {
@@ -118,18 +146,8 @@ static int pool_alloc(smm_ctx *c, size_t bytes, void **out)
         return SMM_OK;
     }
     void *p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) {
-        // drop the cache and retry once
-        for (auto &b : c->pool) (void)hipFree(b.p);
-        c->pool.clear();
-        (void)hipGetLastError();
-        e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(SMM_ERR_ALLOC, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
-        }
-    }
+    hipError_t e = dev_malloc(c, &p, bytes);           // (drops the pool's free blocks and retries once)
+    if (e != hipSuccess) return fail(SMM_ERR_ALLOC, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
     c->live[p] = bytes;
     *out = p;
     return SMM_OK;
@@ -273,6 +291,38 @@ extern "C" int smm_ctx_synchronize(smm_ctx *c)
     CTX_LOCK(c);
     HIPCHK(hipSetDevice(c->device));
     return take_plan_error(c, "smm_ctx_synchronize");       // (synchronises the stream)
+}
+
+extern "C" int smm_ctx_release_pool(smm_ctx *c)
+{
+    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CTX_LOCK(c);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    pool_flush(c);
+    return SMM_OK;
+}
+extern "C" int64_t smm_ctx_pool_bytes(smm_ctx *c)
+{
+    if (!c) return -1;
+    CTX_LOCK(c);
+    int64_t t = 0;
+    for (auto &b : c->pool) t += (int64_t)b.bytes;
+    return t;
+}
+extern "C" int smm_ctx_inject_alloc_failure(smm_ctx *c, int nth, int hard)
+{
+    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CTX_LOCK(c);
+    c->inject_alloc_nth = nth > 0 ? nth : 0;
+    c->inject_alloc_hard = hard != 0;
+    return SMM_OK;
+}
+extern "C" int64_t smm_ctx_alloc_retries(smm_ctx *c)
+{
+    if (!c) return -1;
+    CTX_LOCK(c);
+    return c->alloc_retries;
 }
 
 extern "C" int smm_ctx_set_check(smm_ctx *c, int enable)
@@ -693,9 +743,9 @@ extern "C" int smm_csr_from_host(smm_ctx *c, int64_t rows, int64_t cols, int64_t
     CTX_LOCK(c);
     if (!indptr || (nnz > 0 && (!indices || !data))) return fail(SMM_ERR_INVALID, "NULL CSR array");
     int *dp = nullptr, *di = nullptr; double *dv = nullptr;
-    if (hipMalloc((void **)&dp, (rows + 1) * sizeof(int)) != hipSuccess ||
-        hipMalloc((void **)&di, (std::max<int64_t>(nnz, 1) + 2) * sizeof(int)) != hipSuccess ||     // + slack: the wide symbolic walk reads columns in pairs
-        hipMalloc((void **)&dv, std::max<int64_t>(nnz, 1) * sizeof(double)) != hipSuccess) {
+    if (dev_malloc(c, (void **)&dp, (rows + 1) * sizeof(int)) != hipSuccess ||
+        dev_malloc(c, (void **)&di, (std::max<int64_t>(nnz, 1) + 2) * sizeof(int)) != hipSuccess ||     // + slack: the wide symbolic walk reads columns in pairs
+        dev_malloc(c, (void **)&dv, std::max<int64_t>(nnz, 1) * sizeof(double)) != hipSuccess) {
         (void)hipFree(dp); (void)hipFree(di); (void)hipFree(dv);
         return fail(SMM_ERR_ALLOC, "hipMalloc of a CSR operand failed");
     }
@@ -808,7 +858,7 @@ static int ensure_seg(smm_ctx *c, smm_csr *b, const Geom &g, const int **out)
         if (e.wf == g.wf && e.n_ft == g.n_ft) { *out = e.seg; return SMM_OK; }
     const int64_t total = b->rows * (int64_t)(g.n_ft + 1);
     int *seg = nullptr;
-    if (hipMalloc((void **)&seg, std::max<int64_t>(total, 1) * sizeof(int)) != hipSuccess)
+    if (dev_malloc(c, (void **)&seg, std::max<int64_t>(total, 1) * sizeof(int)) != hipSuccess)
         return fail(SMM_ERR_ALLOC, "hipMalloc of the tile index failed");
     if (total > 0) {
         LAUNCH(c, "smm_segptr", smm_segptr, (total + 255) / 256, 256, 0, (int)b->rows, g.n_ft, g.wf, b->ptr, b->idx, seg);
@@ -826,7 +876,7 @@ static int ensure_idx16(smm_ctx *c, smm_csr *b)
     if (b->idx16) return SMM_OK;
     if (b->cols >= 65535) return fail(SMM_ERR_INVALID, "16-bit column copy needs < 65535 columns");
     // + 2 entries of slack: the wide symbolic walk reads columns in pairs
-    if (hipMalloc((void **)&b->idx16, (std::max<int64_t>(b->nnz, 1) + 2) * sizeof(unsigned short)) != hipSuccess)
+    if (dev_malloc(c, (void **)&b->idx16, (std::max<int64_t>(b->nnz, 1) + 2) * sizeof(unsigned short)) != hipSuccess)
         return fail(SMM_ERR_ALLOC, "hipMalloc of the 16-bit column copy failed");
     if (b->nnz > 0) {
         LAUNCH(c, "smm_idx16", smm_idx16, std::min<int64_t>((b->nnz + 255) / 256, 65536), 256, 0, (int)b->nnz, b->idx, b->idx16);
@@ -845,7 +895,7 @@ static int idx_with_slack(smm_ctx *c, smm_csr *b, const int **out)
     if (b->owned) { *out = b->idx; return SMM_OK; }
     if (!b->idx_pad) {
         const size_t n = (size_t)std::max<int64_t>(b->nnz, 1) + 2;
-        if (hipMalloc((void **)&b->idx_pad, n * sizeof(int)) != hipSuccess)
+        if (dev_malloc(c, (void **)&b->idx_pad, n * sizeof(int)) != hipSuccess)
             return fail(SMM_ERR_ALLOC, "hipMalloc of the padded column copy failed");
         hipError_t e = hipMemsetAsync(b->idx_pad + (n - 2), 0, 2 * sizeof(int), c->stream);
         if (e == hipSuccess && b->nnz > 0)
@@ -863,7 +913,7 @@ static int ensure_loc(smm_ctx *c, smm_csr *b, const Geom &g, const short **out)
         if (e.wc == g.wc) { *out = e.loc; return SMM_OK; }
     if (g.wc > 32767) return fail(SMM_ERR_INVALID, "coarse tile wider than 32767 columns");
     short *loc = nullptr;
-    if (hipMalloc((void **)&loc, std::max<int64_t>(b->nnz, 1) * sizeof(short)) != hipSuccess)
+    if (dev_malloc(c, (void **)&loc, std::max<int64_t>(b->nnz, 1) * sizeof(short)) != hipSuccess)
         return fail(SMM_ERR_ALLOC, "hipMalloc of the tile-local column array failed");
     if (b->nnz > 0) {
         LAUNCH(c, "smm_loc16", smm_loc16, std::min<int64_t>((b->nnz + 255) / 256, 65536), 256, 0, (int)b->nnz, g.wc, b->idx, loc);
@@ -894,7 +944,7 @@ static int ensure_ell(smm_ctx *c, smm_csr *h, int nchunks, int chunk, bool sprea
     if (items >= 0x7fffffff) return fail(SMM_ERR_INVALID, "H too large for the sliced-ELL index (%lld blocks)", (long long)items);
     int64_t *cnt = nullptr;
     CHK(pool_get(c, (size_t)items, &cnt));
-    if (hipMalloc((void **)&h->ell_off, (size_t)(items + 1) * sizeof(int64_t)) != hipSuccess) {
+    if (dev_malloc(c, (void **)&h->ell_off, (size_t)(items + 1) * sizeof(int64_t)) != hipSuccess) {
         pool_free(c, cnt);
         return fail(SMM_ERR_ALLOC, "hipMalloc of the ELL index failed");
     }
@@ -910,8 +960,8 @@ static int ensure_ell(smm_ctx *c, smm_csr *h, int nchunks, int chunk, bool sprea
     HIPCHK(hipStreamSynchronize(c->stream));
     pool_free(c, cnt);
     // + one wave of slack: stage 2 requests step 0 of a block before it knows the block is empty
-    if (hipMalloc((void **)&h->ell_col, (total + WAVE) * sizeof(short)) != hipSuccess ||
-        hipMalloc((void **)&h->ell_val, (total + WAVE) * sizeof(double)) != hipSuccess)
+    if (dev_malloc(c, (void **)&h->ell_col, (total + WAVE) * sizeof(short)) != hipSuccess ||
+        dev_malloc(c, (void **)&h->ell_val, (total + WAVE) * sizeof(double)) != hipSuccess)
         return fail(SMM_ERR_ALLOC, "hipMalloc of the ELL payload (%lld entries) failed", (long long)total);
     E.col = h->ell_col; E.val = h->ell_val;
     if (spread) LAUNCH(c, "smm_ell_fill", smm_ell_fill<1>, grid, 256, 0, E);
@@ -1132,8 +1182,8 @@ static int ensure_pack(smm_ctx *c, smm_csr *b, const Geom &g, smm_csr::PackCache
     smm_csr::PackCache e{g.wc, g.nct, nullptr, nullptr, maxlen};
     // (+ 4 units of slack: the piece walk's last lane reads up to three 8-byte units past a very short last piece)
     if (rc == SMM_OK &&
-        (hipMalloc((void **)&e.desc, (size_t)std::max<int64_t>(cells, 1) * sizeof(int2)) != hipSuccess ||
-         hipMalloc((void **)&e.pay, (size_t)(std::max<int64_t>(total, 1) + 4) * sizeof(double)) != hipSuccess)) {
+        (dev_malloc(c, (void **)&e.desc, (size_t)std::max<int64_t>(cells, 1) * sizeof(int2)) != hipSuccess ||
+         dev_malloc(c, (void **)&e.pay, (size_t)(std::max<int64_t>(total, 1) + 4) * sizeof(double)) != hipSuccess)) {
         (void)hipFree(e.desc); (void)hipFree(e.pay);
         rc = fail(SMM_ERR_ALLOC, "hipMalloc of the packed payload failed");
     }
@@ -1181,8 +1231,8 @@ static int ensure_ccs(smm_ctx *c, smm_csr *b, int ws, int n_slabs, smm_csr::CcsC
     smm_csr::CcsCache e{ws, n_slabs, (ws + 31) / 32, (int)total, nullptr, nullptr};
     const int64_t ptr_entries = (int64_t)n_slabs * (b->rows + 1);
     if (rc == SMM_OK &&
-        (hipMalloc((void **)&e.cptr, (size_t)ptr_entries * sizeof(int)) != hipSuccess ||
-         hipMalloc((void **)&e.stream, (size_t)(total + 1) * CCS_CHUNK * sizeof(unsigned short)) != hipSuccess)) {
+        (dev_malloc(c, (void **)&e.cptr, (size_t)ptr_entries * sizeof(int)) != hipSuccess ||
+         dev_malloc(c, (void **)&e.stream, (size_t)(total + 1) * CCS_CHUNK * sizeof(unsigned short)) != hipSuccess)) {
         (void)hipFree(e.cptr); (void)hipFree(e.stream);
         rc = fail(SMM_ERR_ALLOC, "hipMalloc of the chunked column stream failed");
     }
@@ -1246,9 +1296,9 @@ static int ensure_slab(smm_ctx *c, smm_csr *b, const SlabGeom &g, smm_csr::SlabC
     int rc = pool_get(c, (size_t)cells + 1, &off64);
     if (rc != SMM_OK) { pool_free(c, cnt); return rc; }
     smm_csr::SlabCache e{g.ws, g.n_slabs, nullptr, nullptr, nullptr};
-    if (hipMalloc((void **)&e.soff, (size_t)(cells + 1) * sizeof(int)) != hipSuccess ||
-        hipMalloc((void **)&e.scol, (size_t)std::max<int64_t>(b->nnz, 1) * sizeof(short)) != hipSuccess ||
-        hipMalloc((void **)&e.sval, (size_t)std::max<int64_t>(b->nnz, 1) * sizeof(double)) != hipSuccess) {
+    if (dev_malloc(c, (void **)&e.soff, (size_t)(cells + 1) * sizeof(int)) != hipSuccess ||
+        dev_malloc(c, (void **)&e.scol, (size_t)std::max<int64_t>(b->nnz, 1) * sizeof(short)) != hipSuccess ||
+        dev_malloc(c, (void **)&e.sval, (size_t)std::max<int64_t>(b->nnz, 1) * sizeof(double)) != hipSuccess) {
         (void)hipFree(e.soff); (void)hipFree(e.scol); (void)hipFree(e.sval);
         pool_free(c, cnt); pool_free(c, off64);
         return fail(SMM_ERR_ALLOC, "hipMalloc of the slab-major copy of B failed");
@@ -2302,8 +2352,8 @@ extern "C" int smm_device_malloc(smm_ctx *c, int64_t bytes, void **d_ptr)
     if (!c || !d_ptr || bytes < 0) return fail(SMM_ERR_INVALID, "bad argument");
     CTX_LOCK(c);
     HIPCHK(hipSetDevice(c->device));
-    hipError_t e = hipMalloc(d_ptr, (size_t)std::max<int64_t>(bytes, 16));
-    if (e != hipSuccess) { (void)hipGetLastError(); return fail(SMM_ERR_ALLOC, "hipMalloc(%lld): %s", (long long)bytes, hipGetErrorString(e)); }
+    hipError_t e = dev_malloc(c, d_ptr, (size_t)std::max<int64_t>(bytes, 16));
+    if (e != hipSuccess) { return fail(SMM_ERR_ALLOC, "hipMalloc(%lld): %s", (long long)bytes, hipGetErrorString(e)); }
     return SMM_OK;
 }
 extern "C" int smm_device_free(smm_ctx *c, void *d_ptr)

@@ -179,7 +179,8 @@ def allgather_rows(local, rows_per_rank, dist, group=None):
     import torch
     world, rank = _world(dist, group)
     rows_per_rank = [int(r) for r in rows_per_rank]
-    assert len(rows_per_rank) == world and local.shape[0] == rows_per_rank[rank]
+    if len(rows_per_rank) != world or local.shape[0] != rows_per_rank[rank]:
+        raise ValueError(f"allgather_rows: rank {rank} holds {local.shape[0]} rows, rows_per_rank says {rows_per_rank}")
     n = int(local.shape[1])
     total = sum(rows_per_rank)
     send, back = _stage(local.contiguous(), dist, group)
@@ -189,7 +190,8 @@ def allgather_rows(local, rows_per_rank, dist, group=None):
             dist.all_gather_into_tensor(out, send, group=group)
     else:
         flat, sizes = _allgatherv(send.reshape(-1), dist, group, world, rank, torch)
-        assert sizes == [r * n for r in rows_per_rank]
+        if sizes != [r * n for r in rows_per_rank]:           # (a real check: `python -O` strips asserts)
+            raise RuntimeError(f"allgather_rows: the ranks sent {sizes} elements, expected {[r * n for r in rows_per_rank]}")
         out = flat.reshape(total, n)
     return out.to(back) if back is not None else out
 

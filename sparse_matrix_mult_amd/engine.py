@@ -91,6 +91,20 @@ class Context:
         ds_add_f64 in ascending lane order.  inject_fault=True exercises that failure path."""
         check(self.lib, self.lib.smm_ctx_exact_selftest(self.handle, 1 if inject_fault else 0))
 
+    def release_pool(self):
+        """Return the pooled scratch of destroyed plans / finished calls to the device (smm_ctx_release_pool)."""
+        check(self.lib, self.lib.smm_ctx_release_pool(self.handle))
+
+    def pool_bytes(self):
+        return int(self.lib.smm_ctx_pool_bytes(self.handle))
+
+    def inject_alloc_failure(self, nth, hard=False):
+        """TEST HOOK: the nth device allocation from now fails (first attempt only, or both with hard=True)."""
+        check(self.lib, self.lib.smm_ctx_inject_alloc_failure(self.handle, int(nth), 1 if hard else 0))
+
+    def alloc_retries(self):
+        return int(self.lib.smm_ctx_alloc_retries(self.handle))
+
     def set_check(self, enable=True):
         """Run the plan checker at the end of every symbolic phase (also env SMM_CHECK=1): inconsistent plan
         metadata raises SmmError (SMM_ERR_INTERNAL).  The kernels' own bounds clamps are always on."""
@@ -178,6 +192,33 @@ class Context:
         finally:
             plan.close()
         return indptr, indices, data
+
+    def spgemm_mirrored_torch(self, a, b, exact=False):
+        """spgemm_host_mirrored with the full symmetric CSR left in HBM: (indptr int64, indices int32, data float64)
+        torch tensors."""
+        import torch
+        if a.rows != b.cols:
+            raise ValueError("For symmetric output, the resulting matrix must be square.")
+        n = a.rows
+        dev = torch.device("cuda", self.device)
+        plan = self.spgemm_plan(a, b, symmetric=True, exact=exact)
+        try:
+            up = torch.empty(n + 1, dtype=torch.int64, device=dev)
+            ui = torch.empty(plan.nnz, dtype=torch.int32, device=dev)
+            uv = torch.empty(plan.nnz, dtype=torch.float64, device=dev)
+            plan.numeric_into(up.data_ptr(), ui.data_ptr(), uv.data_ptr())
+        finally:
+            plan.close()
+        fp = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        nnz = ctypes.c_int64()
+        vp = ctypes.c_void_p
+        check(self.lib, self.lib.smm_csr_mirror_symbolic(self.handle, n, vp(up.data_ptr()), vp(ui.data_ptr()), vp(fp.data_ptr()), ctypes.byref(nnz)))
+        fi = torch.empty(nnz.value, dtype=torch.int32, device=dev)
+        fv = torch.empty(nnz.value, dtype=torch.float64, device=dev)
+        check(self.lib, self.lib.smm_csr_mirror_fill(self.handle, n, vp(up.data_ptr()), vp(ui.data_ptr()), vp(uv.data_ptr()), vp(fp.data_ptr()),
+                                                     vp(fi.data_ptr()), vp(fv.data_ptr())))
+        self.synchronize()
+        return fp, fi, fv
 
     def _dmalloc(self, nbytes):
         p = ctypes.c_void_p()

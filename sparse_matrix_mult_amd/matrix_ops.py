@@ -52,6 +52,45 @@ def set_full_symmetric(flag):
     return old
 
 
+# Device-resident results, opt-in: the reference copies every result out of the library into fresh host
+# arrays (sparsemat_to_csr / darray_to_numpy, matrix_ops.py:205-240); at BASELINE configs[1] that copy is 40 GB and
+# 0.8 s behind 32 ms of GPU work.  With set_result_device(True) (or SMM_RESULT_DEVICE=1) the same call leaves the
+# result in HBM: 'dense' and the triple product return a torch.Tensor (float64, cuda), 'sparse' a DeviceCSRResult
+# (indptr int64 / indices int32 / data float64 torch tensors, first-touch order as ever) with .to_scipy() for the
+# reference's return type.  The default is the reference's behaviour: caller-owned host objects.
+_result_device = os.environ.get("SMM_RESULT_DEVICE", "0") not in ("", "0")
+
+
+def set_result_device(flag):
+    """Leave results in HBM as torch tensors (see DeviceCSRResult); returns the old setting."""
+    global _result_device
+    old, _result_device = _result_device, bool(flag)
+    return old
+
+
+class DeviceCSRResult:
+    """A CSR result resident in HBM: .indptr (int64), .indices (int32), .data (float64) are torch CUDA tensors,
+    .shape / .nnz as scipy's.  Columns inside a row are in the reference's first-touch order (not sorted)."""
+    __slots__ = ("indptr", "indices", "data", "shape")
+
+    def __init__(self, indptr, indices, data, shape):
+        self.indptr, self.indices, self.data, self.shape = indptr, indices, data, tuple(shape)
+
+    @property
+    def nnz(self):
+        return int(self.indices.numel())
+
+    def to_scipy(self):
+        """The reference's return type (copies the result to the host)."""
+        return _result_csr(self.indptr.cpu().numpy(), self.indices.cpu().numpy(), self.data.cpu().numpy(), self.shape)
+
+    def to_torch_sparse_csr(self):
+        """torch.sparse_csr_tensor over the same values (torch wants one index dtype: both int64; columns unsorted)."""
+        import torch
+        return torch.sparse_csr_tensor(self.indptr, self.indices.to(torch.int64), self.data, size=self.shape,
+                                       check_invariants=False)
+
+
 def set_exact(flag):
     """Select bit-exact (reference-order) accumulation for later calls; returns the old setting."""
     global _exact
@@ -102,10 +141,13 @@ def _operand_key(m):
 
 
 class _Entry:
-    __slots__ = ("handle", "pattern", "data_key", "users", "refs")
+    # nbytes: HBM of the handle and its cached copies as of its last use (refreshed OUTSIDE _cache_lock: the query takes
+    # the context's lock and would wait for a running product); dead: a PinnedOperand that was unpinned while leased
+    __slots__ = ("handle", "pattern", "data_key", "users", "refs", "nbytes", "dead")
 
     def __init__(self, handle, pattern, data_key):
         self.handle, self.pattern, self.data_key, self.users, self.refs = handle, pattern, data_key, 0, []
+        self.nbytes, self.dead = 0, False
 
     def remember(self, arr):
         self.refs = [r for r in self.refs if r() is not None]
@@ -120,10 +162,10 @@ class _Entry:
 
 
 class _PlanEntry:
-    __slots__ = ("plan", "a", "b", "users")
+    __slots__ = ("plan", "a", "b", "users", "nbytes")
 
-    def __init__(self, plan, a, b):
-        self.plan, self.a, self.b, self.users = plan, a, b, 0
+    def __init__(self, plan, a, b, nbytes=0):
+        self.plan, self.a, self.b, self.users, self.nbytes = plan, a, b, 0, nbytes
 
 
 class _Lease:
@@ -135,10 +177,18 @@ class _Lease:
 
     def release(self):
         if self.entry is not None:
+            ent = self.entry
+            nbytes = ent.handle.device_bytes() if ent.handle is not None else 0      # (library call: before taking _cache_lock)
+            close = None
             with _cache_lock:
-                self.entry.users -= 1
-                if self.entry.users == 0 and self.entry.pattern in _cache:
-                    _trim_locked()               # what had to stay while it was in use may go now
+                ent.nbytes = nbytes
+                ent.users -= 1
+                if ent.users == 0 and ent.dead:
+                    close = ent.handle               # unpinned while this call was using it
+                elif ent.users == 0 and ent.pattern in _cache:
+                    _trim_locked()                   # what had to stay while it was in use may go now
+            if close is not None:
+                close.close()
             self.entry = None
         elif self._transient and self.handle is not None:
             self.handle.close()
@@ -150,17 +200,40 @@ def _drop_entry_locked(key):
     if ent is None:
         return
     for pk in [pk for pk, pe in _plans.items() if pe.a is ent or pe.b is ent]:
-        _plans.pop(pk).plan.close()
-    ent.handle.close()
+        pe = _plans.pop(pk)
+        if pe.users == 0:
+            pe.plan.close()                      # (else: _release_plan closes it when the call that runs it ends)
+    if ent.users == 0:
+        ent.handle.close()
+    else:
+        ent.dead = True                          # leased by a running call: its release closes the handle
 
 
 def _cached_bytes_locked():
-    return sum(e.handle.device_bytes() for e in _cache.values()) + sum(pe.plan.device_bytes() for pe in _plans.values())
+    # (byte counts recorded on the entries: no library call -- it would take the context's lock -- under _cache_lock)
+    return sum(e.nbytes for e in _cache.values()) + sum(pe.nbytes for pe in _plans.values())
+
+
+_graveyard = []          # PinnedOperands dropped by the garbage collector: closed by the next _trim_locked (list.append is atomic)
+
+
+def _bury_locked():
+    while _graveyard:
+        ent = _graveyard.pop()
+        for pk in [pk for pk, pe in _plans.items() if pe.a is ent or pe.b is ent]:
+            pe = _plans.pop(pk)
+            if pe.users == 0:
+                pe.plan.close()                  # (a plan in use is closed by _release_plan when its call ends)
+        if ent.users == 0 and ent.handle is not None:
+            ent.handle.close()
+        else:
+            ent.dead = True                      # closed by the lease that still holds it
 
 
 def _trim_locked(keep=(), reserve=0, protect=()):
     """Enforce the limits (entries idle and not in `keep` only); reserve = entries about to be added; protect =
     pattern keys this call is about to look up (its other operand)."""
+    _bury_locked()
     for key in [k for k, e in _cache.items() if e.users == 0 and e.orphaned() and e not in keep and k not in protect]:
         _drop_entry_locked(key)                  # the arrays it was made from are gone
 
@@ -197,28 +270,51 @@ def _acquire(ctx, m, key=None, protect=()):
         if ent is not None and (not ent.handle.handle or ent.handle.ctx is not ctx):
             _drop_entry_locked(pattern)
             ent = None
+        update = False
         if ent is not None:
             if ent.data_key != data_key:
-                if ent.users > 0:                # another call is multiplying with the old values right now
-                    cache_stats["upload"] += 1
-                    return _Lease(ctx.csr_from_scipy(m), transient=True)
-                ent.handle.update_values(m.data[:ent.handle.nnz])
-                ent.data_key = data_key
-                cache_stats["values_update"] += 1
+                if ent.users > 0:                # another call is multiplying with (or uploading) other values right now
+                    ent = None
+                else:
+                    update = True
+                    ent.data_key = None          # in flux: nobody else may take it for a hit until the values are in HBM
             else:
                 cache_stats["hit"] += 1
-            ent.users += 1
-            ent.remember(m.data)
-            _cache.move_to_end(pattern)
+            if ent is not None:
+                ent.users += 1
+                ent.remember(m.data)
+                _cache.move_to_end(pattern)
+                if not update:
+                    _trim_locked(keep=(ent,), protect=protect)
+                    return _Lease(ent.handle, entry=ent)
+        elif pattern not in _cache:
+            _trim_locked(reserve=1, protect=protect)     # make room before the upload
+        busy = ent is None and pattern in _cache
+    if update:
+        # the host-to-device copy (200 MB at BASELINE configs[1]) runs WITHOUT _cache_lock: the entry is marked in use
+        try:
+            ent.handle.update_values(m.data[:ent.handle.nnz])
+        except BaseException:
+            with _cache_lock:
+                ent.users -= 1
+                if _cache.get(pattern) is ent:
+                    _drop_entry_locked(pattern)
+            raise
+        with _cache_lock:
+            ent.data_key = data_key
+            cache_stats["values_update"] += 1
             _trim_locked(keep=(ent,), protect=protect)
-            return _Lease(ent.handle, entry=ent)
-        _trim_locked(reserve=1, protect=protect)     # make room before the upload
+        return _Lease(ent.handle, entry=ent)
     h = ctx.csr_from_scipy(m)
     cache_stats["upload"] += 1
+    if busy:
+        return _Lease(h, transient=True)
+    nbytes = h.device_bytes()
     with _cache_lock:
         if pattern in _cache:                    # another thread was faster: use ours for this call only
             return _Lease(h, transient=True)
         ent = _Entry(h, pattern, data_key)
+        ent.nbytes = nbytes
         ent.users = 1
         ent.remember(m.data)
         _cache[pattern] = ent
@@ -246,11 +342,12 @@ def _plan_for(ctx, la, lb, symmetric, exact):
     plan = ctx.spgemm_plan(la.handle, lb.handle, symmetric=symmetric, exact=exact)
     if key is None:
         return plan, plan.close
+    nbytes = plan.device_bytes()
     with _cache_lock:
         old = _plans.pop(key, None)
         if old is not None and old.users == 0:
             old.plan.close()
-        pe = _PlanEntry(plan, la.entry, lb.entry)
+        pe = _PlanEntry(plan, la.entry, lb.entry, nbytes)
         pe.users = 1
         _plans[key] = pe
         _trim_locked(keep=(la.entry, lb.entry))
@@ -265,19 +362,24 @@ def _release_plan(pe):
 
 
 def clear_cache():
-    """Forget every cached operand and plan (their HBM is released; handles in use by a running call are
-    released when that call ends)."""
+    """Forget every cached operand and plan and return their HBM to the device: the handles are destroyed, and the
+    scratch of the closed plans -- which the library keeps pooled for reuse -- is released too (smm_ctx_release_pool).
+    Handles in use by a running call are released when that call ends."""
+    ctxs = {}
     with _cache_lock:
+        _bury_locked()
         for pk in list(_plans):
             pe = _plans.pop(pk)
+            ctxs[id(getattr(pe.plan, "ctx", None))] = getattr(pe.plan, "ctx", None)
             if pe.users == 0:
                 pe.plan.close()
         for key in list(_cache):
-            ent = _cache[key]
-            if ent.users == 0:
-                _drop_entry_locked(key)
-            else:
-                _cache.pop(key)                  # still leased: the last reference frees it (DeviceCSR.__del__)
+            ctxs[id(getattr(_cache[key].handle, "ctx", None))] = getattr(_cache[key].handle, "ctx", None)
+            _drop_entry_locked(key)              # (an entry still leased is closed by that lease's release)
+    for c in ctxs.values():
+        release = getattr(c, "release_pool", None)
+        if release is not None and getattr(c, "handle", None):
+            release()
 
 
 def set_operand_cache(entries):
@@ -314,23 +416,73 @@ class PinnedOperand:
         return _Lease(self._handle, entry=self._entry)
 
     def unpin(self):
+        """Release the operand.  Plans made on it leave the cache (one that a running call is using is closed when that
+        call ends); the handle is closed now, or -- while a call still multiplies with it -- by that call's release."""
+        close = None
         with _cache_lock:
             for pk in [pk for pk, pe in _plans.items() if pe.a is self._entry or pe.b is self._entry]:
-                _plans.pop(pk).plan.close()
-        if self._handle is not None:
-            self._handle.close()
-        self._handle = None
+                pe = _plans.pop(pk)
+                if pe.users == 0:
+                    pe.plan.close()
+            if self._entry.users > 0:
+                self._entry.dead = True
+            else:
+                close = self._handle
+            self._handle = None
+        if close is not None:
+            close.close()
 
     def __del__(self):
-        try:
-            self.unpin()
-        except Exception:
-            pass
+        # (may run inside any allocation, also while _trim_locked walks _plans: only leave a note; the next
+        # _trim_locked / clear_cache closes the plans and the handle)
+        if getattr(self, "_handle", None) is not None:
+            _graveyard.append(self._entry)
 
 
 def pin_operand(matrix):
     """Upload `matrix` once and keep it (and everything derived from it) in HBM until unpin()."""
     return PinnedOperand(default_context(), matrix)
+
+
+def _device_zeros(ctx, shape, sparse):
+    import torch
+    dev = torch.device("cuda", ctx.device)
+    if not sparse:
+        return torch.zeros(shape, dtype=torch.float64, device=dev)
+    return DeviceCSRResult(torch.zeros(shape[0] + 1, dtype=torch.int64, device=dev), torch.empty(0, dtype=torch.int32, device=dev),
+                           torch.empty(0, dtype=torch.float64, device=dev), shape)
+
+
+def _product_on_device(ctx, la, lb, triple, output_format, symmetric, compute_full_matrix):
+    """The product of two leased operands with the result left in HBM (torch tensors).  The library works on the
+    context's own stream: torch's current stream is drained first (its allocator may hand out memory that kernels
+    queued there still use) and the context is synchronised before the tensors are returned -- which also reports
+    anything the kernels' bounds clamps recorded (SMM_ERR_INTERNAL)."""
+    import torch
+    dev = torch.device("cuda", ctx.device)
+    a, b = la.handle, lb.handle
+    torch.cuda.current_stream(dev).synchronize()
+    if triple:
+        mirror = compute_full_matrix == 'mirror' or (_full_symmetric and compute_full_matrix == 0)
+        out = torch.empty((a.rows, a.rows), dtype=torch.float64, device=dev)
+        ctx.triple_into(a, b, out.data_ptr(), full=(compute_full_matrix == 1), exact=_exact, mirror=mirror)
+    elif output_format == 'dense':
+        out = torch.empty((a.rows, b.cols), dtype=torch.float64, device=dev)
+        ctx.dense_into(a, b, out.data_ptr(), symmetric=symmetric, exact=_exact, mirror=symmetric and _full_symmetric)
+    elif symmetric and _full_symmetric:
+        out = DeviceCSRResult(*ctx.spgemm_mirrored_torch(a, b, exact=_exact), (a.rows, b.cols))
+    else:
+        plan, release = _plan_for(ctx, la, lb, symmetric, _exact)
+        try:
+            indptr = torch.empty(a.rows + 1, dtype=torch.int64, device=dev)
+            indices = torch.empty(plan.nnz, dtype=torch.int32, device=dev)
+            data = torch.empty(plan.nnz, dtype=torch.float64, device=dev)
+            plan.numeric_into(indptr.data_ptr(), indices.data_ptr(), data.data_ptr())
+        finally:
+            release()
+        out = DeviceCSRResult(indptr, indices, data, (a.rows, b.cols))
+    ctx.synchronize()
+    return out
 
 
 def _as_csr(x):
@@ -393,6 +545,8 @@ def sparse_matrix_multiply(matrix_a, matrix_b, output_format='sparse', symmetric
 
     out_shape = (matrix_a.shape[0], matrix_b.shape[1])
     if matrix_a.nnz == 0 or matrix_b.nnz == 0:               # reference :315-319
+        if _result_device:
+            return _device_zeros(default_context(), out_shape, output_format == 'sparse')
         return csr_matrix(out_shape) if output_format == 'sparse' else np.zeros(out_shape)
 
     if symmetric and out_shape[0] != out_shape[1]:           # reference :321-322
@@ -415,6 +569,8 @@ def sparse_matrix_multiply(matrix_a, matrix_b, output_format='sparse', symmetric
             lb = _acquire(ctx, matrix_b, key_b)
             try:
                 a, b = la.handle, lb.handle
+                if _result_device:
+                    return _product_on_device(ctx, la, lb, use_triple_product, output_format, bool(symmetric), compute_full_matrix)
                 if use_triple_product:                           # reference :325-336
                     mirror = compute_full_matrix == 'mirror' or (_full_symmetric and compute_full_matrix == 0)
                     return ctx.triple_host(a, b, full=(compute_full_matrix == 1), exact=_exact, mirror=mirror)
@@ -444,6 +600,11 @@ def sparse_matrix_multiply(matrix_a, matrix_b, output_format='sparse', symmetric
         clear_cache()                                            # the resident operands / plans were in the way
         result = product()
 
+    if _result_device and not isinstance(result, (np.ndarray, csr_matrix)):
+        empty = result.nnz == 0 if isinstance(result, DeviceCSRResult) else not bool(result.any())
+        if empty:
+            print("Multiplication resulted in a zero matrix.")
+        return result
     if isinstance(result, np.ndarray):                       # reference :370-373
         # (the first row decides almost always; a full scan of a 20 GB result costs 0.7 s)
         if not (result[:1].any() or result.any()):

@@ -242,3 +242,45 @@ def test_exact_guard_blocks_exact_products_when_it_fails(oracle, monkeypatch):
         assert_csr_equal(got, oracle.sparse(arrays(A), arrays(B), 70), values="tol")
     finally:
         a.close(); b.close(); c.close()
+
+
+def test_a_failed_allocation_is_retried_after_the_pool_went_back_to_the_device(pkg, oracle):
+    """destroyed plans leave their multi-GB lists in the context's pool, which only pool allocations used to
+    flush.  Now every device allocation that fails flushes the pool and retries once (no sticky HIP error is left
+    behind), clear_cache() releases the pool, and a hard failure reaches sparse_matrix_multiply()'s own retry
+    (SMM_ERR_ALLOC -> clear_cache -> once more)."""
+    from sparse_matrix_mult_amd.engine import SmmError, default_context
+    ctx = default_context()
+    smm = pkg.sparse_matrix_multiply
+    A, B = rand_csr(300, 400, 0.05, 31), rand_csr(400, 500, 0.05, 32)
+    _check(smm(A, B), A, B, oracle)
+    pkg.clear_cache()
+    assert ctx.pool_bytes() == 0                                   # the closed plan's lists left the pool as well
+    # (1) the first attempt of an allocation of a fresh operand's upload fails: the library retries by itself
+    before = ctx.alloc_retries()
+    ctx.inject_alloc_failure(2)
+    A2, B2 = rand_csr(300, 400, 0.05, 33), rand_csr(400, 500, 0.05, 34)
+    _check(smm(A2, B2), A2, B2, oracle)
+    assert ctx.alloc_retries() == before + 1
+    # (2) a cached copy built during the symbolic phase (packed payload / tile index) fails the same way
+    ctx.inject_alloc_failure(1)
+    _check(smm(A2, B2, symmetric=False), A2, B2, oracle)           # operands cached; plan cached -> force a new geometry instead:
+    a, b = ctx.csr_from_scipy(A2), ctx.csr_from_scipy(B2)
+    try:
+        ctx.inject_alloc_failure(3)
+        assert_csr_equal(ctx.spgemm_host(a, b, exact=True), oracle.sparse(arrays(A2), arrays(B2), 500), values="bits")
+        # (3) both attempts fail: SMM_ERR_ALLOC through the C ABI, nothing sticky behind it
+        ctx.inject_alloc_failure(1, hard=True)
+        a3 = None
+        with pytest.raises(SmmError) as e:
+            a3 = ctx.csr_from_scipy(A)
+        assert e.value.code == -3 and a3 is None
+        assert_csr_equal(ctx.spgemm_host(a, b, exact=True), oracle.sparse(arrays(A2), arrays(B2), 500), values="bits")
+    finally:
+        a.close(); b.close()
+    # (4) ... and through the public entry point: the call drops what is resident and succeeds on its second try
+    A4, B4 = rand_csr(300, 400, 0.05, 35), rand_csr(400, 500, 0.05, 36)
+    _check(smm(A4, B2), A4, B2, oracle)                            # something is resident now
+    ctx.inject_alloc_failure(1, hard=True)
+    _check(smm(A4, B4), A4, B4, oracle)
+    ctx.inject_alloc_failure(0)

@@ -82,6 +82,30 @@ def test_bench_launches_its_own_ranks_and_gathers(tmp_path):
         assert line["gather_ms" if extra else "exchange_ms"] >= 0.0
 
 
+def test_bench_rehearsal_of_the_config4_shape_verifies_against_one_gpu():
+    """Round 4 (first-contact safety): the N > 1 bench line on a small instance of BASELINE configs[4]'s shape (2000 rows
+    per rank, B 70 000 columns wide: beyond one slab of the symbolic walk, so the column-slab kernels of the real
+    configs[4] run) -- weak scaling with the exchange step, and --gather with the all-gatherv -- carries the rccl /
+    exchange_ms / gather_ms fields, and `--verify` shows that what the ranks exchanged / gathered, concatenated in rank
+    order, IS the single-GPU CSR of the concatenated row blocks (src/sparse_sparse_sparse.cpp:235-241,269-291)."""
+    import json
+    import subprocess
+    env = dict(os.environ, SMM_BENCH_REHEARSAL="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    for extra in ([], ["--gather"], ["--gather", "--exact"]):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c4", "--steps", "2", "--warmup", "1",
+                              "--rows", "2000", "--cols", "70000", "--no-cpu", "--verify"] + extra,
+                             env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+        assert line["n_gpus"] == 2 and line["rccl"]["world"] == 2 and line["rccl"]["backend"] == "gloo"
+        assert line["gather_ms" if "--gather" in extra else "exchange_ms"] >= 0.0
+        assert line["verify"]["global_indptr_equals_single_gpu"] is True
+        if "--gather" in extra:
+            assert line["verify"]["gathered_indices_equal_single_gpu"] is True
+            assert line["verify"]["gathered_values_equal_single_gpu"] is True
+
+
 def test_two_ranks_reassemble_the_single_device_csr():
     import torch.multiprocessing as mp
     port = _free_port()

@@ -246,3 +246,75 @@ def test_cache_policy_limits_orphans_and_leases(cache):
     mo._cache_max_bytes = 1
     lz = mo._acquire(ctx, mats[2]); lz.release()
     assert len(mo._cache) == 0 and len(mo._plans) == 0
+
+
+# ---- round 4: lock hygiene of the operand cache, unpin while leased, pool release
+def test_values_upload_runs_outside_the_cache_lock_and_clear_cache_releases_the_pool(cache):
+    """A values-only update (a 200 MB host-to-device copy at BASELINE configs[1]) must not stall callers that need no
+    cache state of that entry: while one thread is inside update_values, another thread's acquire / release of a
+    different operand completes.  clear_cache() hands the library's pooled scratch back (smm_ctx_release_pool)."""
+    import threading
+    mo = cache
+    gate, inside = threading.Event(), threading.Event()
+
+    class SlowHandle(_FakeHandle):
+        def update_values(self, data):
+            inside.set()
+            assert gate.wait(20), "the other thread never got through: the cache lock was held across the upload"
+            super().update_values(data)
+
+    class Ctx(_FakeCtx):
+        released = 0
+
+        def csr_from_scipy(self, m):
+            self.uploads += 1
+            return SlowHandle(self, m)
+
+        def release_pool(self):
+            Ctx.released += 1
+
+    ctx = Ctx()
+    ctx.handle = object()
+    B, other = _rand(40, 50, 2), _rand(30, 40, 3)
+    mo._acquire(ctx, B).release()
+    B2 = B.copy(); B2.data += 1.0
+    done = []
+
+    def updater():
+        lease = mo._acquire(ctx, B2)                  # same pattern, new values: update path
+        done.append(np.array_equal(lease.handle.values, B2.data))
+        lease.release()
+
+    t = threading.Thread(target=updater); t.start()
+    assert inside.wait(20)
+    # the entry is busy: the same pattern with yet other values gets a private upload instead of waiting
+    B3 = B.copy(); B3.data += 2.0
+    l3 = mo._acquire(ctx, B3); assert l3.entry is None; l3.release()
+    lo = mo._acquire(ctx, other); lo.release()        # an unrelated operand goes straight through
+    gate.set(); t.join(20)
+    assert done == [True] and mo.cache_stats["values_update"] == 1
+    mo.clear_cache()
+    assert Ctx.released >= 1 and len(mo._cache) == 0
+
+
+def test_unpin_while_leased_defers_the_close_and_gc_only_leaves_a_note(cache):
+    import gc
+    mo = cache
+    ctx = _FakeCtx()
+    P = mo.PinnedOperand(ctx, _rand(30, 40, 5))
+    B = _rand(40, 50, 6)
+    lp = mo._acquire(ctx, P); lb = mo._acquire(ctx, B)
+    handle = lp.handle
+    P.unpin()                                         # a product is running with it
+    assert handle.handle is not None                  # ... so the device handle is still alive
+    lb.release(); lp.release()
+    assert handle.handle is None                      # closed by the lease that held it
+    with pytest.raises(ValueError):
+        mo._acquire(ctx, P)
+    # garbage collection of a pinned operand never touches the cache structures itself
+    Q = mo.PinnedOperand(ctx, _rand(30, 40, 7))
+    qh = Q._handle
+    del Q; gc.collect()
+    assert qh.handle is not None and len(mo._graveyard) == 1
+    mo._acquire(ctx, B).release()                     # the next trim buries it
+    assert qh.handle is None and not mo._graveyard
