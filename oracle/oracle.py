@@ -31,7 +31,8 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "liboracle.so")
+        # SMM_ORACLE_LIB: another build of the same restatement (scripts/sanitize_cpu.sh: ASan/UBSan)
+        path = os.environ.get("SMM_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(path):
             build()
         L = ctypes.CDLL(path)

@@ -107,6 +107,10 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
     return v;
 }
+// EXEC convention of every hand-issued block in this file: the block narrows EXEC and restores it to -1, i.e. it must
+// be reached with ALL 64 lanes active.  That holds by construction: every kernel is launched with a block size that
+// is a multiple of 64 (__launch_bounds__ + the host's launch code), and the blocks sit in wave-uniform control flow
+// (loop bounds and conditions are readfirstlane'd / ballot results), never under a per-lane branch.
 // Hand-issued memory operations for loops whose order of issue matters more than the compiler's view of
 // them (it sinks loads into the branch of their first use, or turns selects back into branches).  The
 // compiler does not know these are in flight: a value loaded by gload_* must be defined ONCE and read only behind
@@ -1613,14 +1617,14 @@ __device__ __forceinline__ void smm_accumulate_pieces(const NumericArgs &A, doub
                                  "global_load_dwordx4 %1, %3, %5 offset:16\n\t"
                                  "global_load_dwordx2 %2, %4, %6\n\t"
                                  "s_mov_b64 exec, -1"
-                                 : "=v"(v0[u]), "=v"(v1[u]), "=v"(cc[u])
-                                 : "v"(voff), "v"(coff), "s"(vb), "s"(cb), "s"(lm) : "memory");
+                                 : "=&v"(v0[u]), "=&v"(v1[u]), "=&v"(cc[u])      // early-clobber: no output may share a register with voff / coff,
+                                 : "v"(voff), "v"(coff), "s"(vb), "s"(cb), "s"(lm) : "memory");   // which the later loads of the block still read
                 else
                     asm volatile("s_mov_b64 exec, %6\n\t"
                                  "global_load_dwordx4 %0, %2, %4\n\t"
                                  "global_load_dword %1, %3, %5\n\t"
                                  "s_mov_b64 exec, -1"
-                                 : "=v"(v0[u]), "=v"(cc[u].x)
+                                 : "=&v"(v0[u]), "=&v"(cc[u].x)
                                  : "v"(voff), "v"(coff), "s"(vb), "s"(cb), "s"(lm) : "memory");
             }
 #pragma unroll
