@@ -50,8 +50,9 @@ enum smm_flags {
                              (what compute_full_matrix=1 was meant to give; SMM_FULL_MATRIX reproduces its
                              doubling bug instead).  Whole square results only.                          */
     SMM_EXACT       = 4   /* add every product in exactly the reference's order: float64 values
-                             are then bit-identical to the CPU loop (for operands with sorted
-                             rows).  Without it the numeric phase lets the waves of a workgroup
+                             are then bit-identical to the CPU loop, for any legal CSR operand (B with
+                             unsorted rows or repeated columns takes an ordered read-modify-write
+                             path instead of the tile kernels: exact, not fast).  Without it the numeric phase lets the waves of a workgroup
                              add concurrently (LDS atomics): values agree to rounding -- tested
                              to the north star's 1e-10 relative -- and the kernel is ~3x faster.
                              indptr / indices are bit-exact in both modes.                     */

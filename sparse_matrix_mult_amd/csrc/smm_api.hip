@@ -1972,15 +1972,15 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
         LAUNCH_CHECK();
         const int grid = (int)std::min<int64_t>((nd + 3) / 4, (int64_t)c->n_cu * 2);
         int *slot = nullptr;
-        CHK(pool_get(c, (size_t)grid * 4 * (size_t)p->ncols, &slot));
-        if (sym)
-            LAUNCH(c, "smm_numeric_general", smm_numeric_general<true>, grid, 256, 0, nd, (int)p->ncols,
-                   p->row_offset, dense_rows, p->a->ptr, p->a->idx, p->a->val, p->b->ptr, p->b->idx, p->b->val, p->d_cptr,
+        // SMM_EXACT: the ordered variant (read-modify-write in the reference's order instead of atomics; a second map per wave)
+        CHK(pool_get(c, (size_t)grid * 4 * (size_t)p->ncols * (exact ? 2 : 1), &slot));
+#define GEN_CASE(S, O)                                                                                                        \
+        if (sym == S && exact == O)                                                                                           \
+            LAUNCH(c, "smm_numeric_general", (smm_numeric_general<S, O>), grid, 256, 0, nd, (int)p->ncols, p->row_offset,      \
+                   dense_rows, p->a->ptr, p->a->idx, p->a->val, p->b->ptr, p->b->idx, p->b->val, p->d_cptr,                   \
                    (const int *)d_c_indices, d_c_data, slot);
-        else
-            LAUNCH(c, "smm_numeric_general", smm_numeric_general<false>, grid, 256, 0, nd, (int)p->ncols,
-                   p->row_offset, dense_rows, p->a->ptr, p->a->idx, p->a->val, p->b->ptr, p->b->idx, p->b->val, p->d_cptr,
-                   (const int *)d_c_indices, d_c_data, slot);
+        GEN_CASE(false, false) GEN_CASE(true, false) GEN_CASE(false, true) GEN_CASE(true, true)
+#undef GEN_CASE
         LAUNCH_CHECK();
         HIPCHK(hipStreamSynchronize(c->stream));
         pool_free(c, slot);
@@ -2070,14 +2070,19 @@ static int dense_into(smm_ctx *c, smm_csr *a, smm_csr *b, int flags, int64_t row
         A.c_dense = d_c; A.ldc = ldc;
         CHK(launch_numeric<OUT_DENSE>(c, A, sym, g.nw, (flags & SMM_EXACT) != 0));
     } else {
-        const int grid = (int)std::min<int64_t>((m + 3) / 4, 65536);
-        if (sym)
-            LAUNCH(c, "smm_dense_general", smm_dense_general<true>, grid, 256, 0, (int)m, (int)n, row_offset, a->ptr,
-                   a->idx, a->val, b->ptr, b->idx, b->val, d_c, ldc);
-        else
-            LAUNCH(c, "smm_dense_general", smm_dense_general<false>, grid, 256, 0, (int)m, (int)n, row_offset, a->ptr,
-                   a->idx, a->val, b->ptr, b->idx, b->val, d_c, ldc);
-        LAUNCH_CHECK();
+        const bool ordered = (flags & SMM_EXACT) != 0;
+        const int grid = (int)std::min<int64_t>((m + 3) / 4, ordered ? (int64_t)c->n_cu * 2 : 65536);
+        int *owner = nullptr;
+        if (ordered) CHK(pool_get(c, (size_t)grid * 4 * (size_t)n, &owner));
+#define GEN_CASE(S, O)                                                                                                        \
+        if (sym == S && ordered == O)                                                                                         \
+            LAUNCH(c, "smm_dense_general", (smm_dense_general<S, O>), grid, 256, 0, (int)m, (int)n, row_offset, a->ptr, a->idx, \
+                   a->val, b->ptr, b->idx, b->val, d_c, ldc, owner);
+        GEN_CASE(false, false) GEN_CASE(true, false) GEN_CASE(false, true) GEN_CASE(true, true)
+#undef GEN_CASE
+        hipError_t e = hipGetLastError();
+        if (owner) { if (e == hipSuccess) e = hipStreamSynchronize(c->stream); pool_free(c, owner); }
+        if (e != hipSuccess) return fail(SMM_ERR_HIP, "smm_dense_general: %s", hipGetErrorString(e));
     }
     return SMM_OK;
 }

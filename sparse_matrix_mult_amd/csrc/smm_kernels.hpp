@@ -2085,7 +2085,45 @@ __global__ __launch_bounds__(256) void smm_copy_lists(int m, const int *__restri
 // then not contiguous).  One wave per row, the reference's own structure: a column -> slot
 // map in HBM (workArray, sparsework.cpp:45) and one global f64 atomic per product.  Values
 // agree to rounding (atomics), indices are untouched.  Correctness path, not a fast path.
-template <bool SYM>
+// ORDERED (SMM_EXACT): the wave that owns the row applies its products strictly in the reference's order
+// (sparsework.cpp:59-76) with plain read-modify-write instead of atomics: one 64-entry piece of B's row per step,
+// every step's stores acknowledged by L2 before the next step's loads (both bypass the L1), and lanes of ONE step
+// that meet on the same accumulator -- a row of B that repeats a column -- go one after the other in ascending lane
+// order.  Bit-identical values for any legal CSR operand; a correctness path, not a fast path.
+__device__ __forceinline__ double ld_l2(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_l2(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ordered_add(double *acc, int *owner, int slot, bool keep, double prod, int lane)
+{
+    // who else of this step adds to my accumulator?  (last writer of owner[slot] wins; everybody else is a loser)
+    if (keep) __hip_atomic_store(&owner[slot], lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    const bool lone = !keep || __hip_atomic_load(&owner[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == lane;
+    unsigned long long clash = __ballot(!lone);
+    if (clash == 0ull) {                                      // the usual step: all accumulators distinct
+        if (keep) st_l2(&acc[slot], ld_l2(&acc[slot]) + prod);
+    } else {
+        // some accumulator is shared: every lane whose accumulator is shared with ANY other lane of the step takes
+        // its turn in ascending lane order (the winners of those accumulators included); the others go together first
+        unsigned long long shared = 0ull;
+        while (clash) {
+            const int x = __ffsll((long long)clash) - 1;
+            const int sx = __shfl(slot, x);
+            const unsigned long long grp = __ballot(keep && slot == sx);
+            shared |= grp; clash &= ~grp;
+        }
+        if (keep && !((shared >> lane) & 1ull)) st_l2(&acc[slot], ld_l2(&acc[slot]) + prod);
+        __threadfence();
+        while (shared) {
+            const int x = __ffsll((long long)shared) - 1;
+            if (lane == x) st_l2(&acc[slot], ld_l2(&acc[slot]) + prod);
+            __threadfence();
+            shared &= shared - 1ull;
+        }
+    }
+    __threadfence();                                          // the stores have reached L2 before the next step loads
+}
+
+template <bool SYM, bool ORDERED = false>
 __global__ __launch_bounds__(256) void smm_numeric_general(int m, int ncols, int64_t row_offset,
                                                            const int *__restrict__ rowlist,
                                                            const int *__restrict__ a_ptr,
@@ -2101,7 +2139,9 @@ __global__ __launch_bounds__(256) void smm_numeric_general(int m, int ncols, int
 {
     const int lane = lane_id();
     const int wpb = blockDim.x / WAVE;
-    int *map = slotmap + ((size_t)blockIdx.x * wpb + (threadIdx.x >> 6)) * (size_t)ncols;
+    // ORDERED: two maps per wave -- column -> slot, and slot -> last lane of the current step (ordered_add)
+    int *map = slotmap + ((size_t)blockIdx.x * wpb + (threadIdx.x >> 6)) * (size_t)ncols * (ORDERED ? 2 : 1);
+    int *owner = map + ncols;
     for (int ri = blockIdx.x * wpb + (threadIdx.x >> 6); ri < m; ri += gridDim.x * wpb) {
         const int row = rowlist ? rowlist[ri] : ri;
         const int64_t rs = c_ptr[row];
@@ -2112,17 +2152,27 @@ __global__ __launch_bounds__(256) void smm_numeric_general(int m, int ncols, int
         for (int j = a_ptr[row]; j < a_ptr[row + 1]; ++j) {
             const int r = a_idx[j];
             const double a = a_val[j];
-            for (int k = b_ptr[r] + lane; k < b_ptr[r + 1]; k += WAVE) {
-                const int c = b_idx[k];
-                if (SYM && (int64_t)c < gi) continue;
-                glb_add(&c_val[rs + map[c]], a * b_val[k]);
+            if constexpr (ORDERED) {
+                for (int k0 = b_ptr[r]; k0 < b_ptr[r + 1]; k0 += WAVE) {         // wave-uniform trip count
+                    const int k = k0 + lane;
+                    const bool in = k < b_ptr[r + 1];
+                    const int c = in ? b_idx[k] : 0;
+                    const bool keep = in && !(SYM && (int64_t)c < gi);
+                    ordered_add(c_val + rs, owner, keep ? map[c] : 0, keep, keep ? a * b_val[k] : 0.0, lane);
+                }
+            } else {
+                for (int k = b_ptr[r] + lane; k < b_ptr[r + 1]; k += WAVE) {
+                    const int c = b_idx[k];
+                    if (SYM && (int64_t)c < gi) continue;
+                    glb_add(&c_val[rs + map[c]], a * b_val[k]);
+                }
             }
         }
         __threadfence();
     }
 }
 
-template <bool SYM>
+template <bool SYM, bool ORDERED = false>
 __global__ __launch_bounds__(256) void smm_dense_general(int m, int ncols, int64_t row_offset,
                                                          const int *__restrict__ a_ptr,
                                                          const int *__restrict__ a_idx,
@@ -2130,10 +2180,11 @@ __global__ __launch_bounds__(256) void smm_dense_general(int m, int ncols, int64
                                                          const int *__restrict__ b_ptr,
                                                          const int *__restrict__ b_idx,
                                                          const double *__restrict__ b_val,
-                                                         double *__restrict__ c, int64_t ldc)
+                                                         double *__restrict__ c, int64_t ldc, int *__restrict__ owner_all)
 {
     const int lane = lane_id();
     const int wpb = blockDim.x / WAVE;
+    int *owner = ORDERED ? owner_all + ((size_t)blockIdx.x * wpb + (threadIdx.x >> 6)) * (size_t)ncols : nullptr;
     for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < m; row += gridDim.x * wpb) {
         double *dst = c + (int64_t)row * ldc;
         const int64_t gi = row + row_offset;
@@ -2142,10 +2193,20 @@ __global__ __launch_bounds__(256) void smm_dense_general(int m, int ncols, int64
         for (int j = a_ptr[row]; j < a_ptr[row + 1]; ++j) {
             const int r = a_idx[j];
             const double a = a_val[j];
-            for (int k = b_ptr[r] + lane; k < b_ptr[r + 1]; k += WAVE) {
-                const int cb = b_idx[k];
-                if (SYM && (int64_t)cb < gi) continue;
-                glb_add(&dst[cb], a * b_val[k]);
+            if constexpr (ORDERED) {
+                for (int k0 = b_ptr[r]; k0 < b_ptr[r + 1]; k0 += WAVE) {
+                    const int k = k0 + lane;
+                    const bool in = k < b_ptr[r + 1];
+                    const int cb = in ? b_idx[k] : 0;
+                    const bool keep = in && !(SYM && (int64_t)cb < gi);
+                    ordered_add(dst, owner, keep ? cb : 0, keep, keep ? a * b_val[k] : 0.0, lane);
+                }
+            } else {
+                for (int k = b_ptr[r] + lane; k < b_ptr[r + 1]; k += WAVE) {
+                    const int cb = b_idx[k];
+                    if (SYM && (int64_t)cb < gi) continue;
+                    glb_add(&dst[cb], a * b_val[k]);
+                }
             }
         }
     }

@@ -168,6 +168,8 @@ def test_sparse_unsorted_and_duplicate_inputs(ctx, oracle):
     assert_csr_equal(_gpu_sparse(ctx, Au, B), want, values="tol", rtol=RTOL)
     want = oracle.sparse(arrays(Au), arrays(Bu), 400)
     assert_csr_equal(_gpu_sparse(ctx, Au, Bu), want, values="tol", rtol=RTOL)
+    # round 4: SMM_EXACT keeps its promise for unsorted B too (ordered read-modify-write instead of atomics)
+    assert_csr_equal(_gpu_sparse(ctx, Au, Bu, exact=True), want, values="bits")
     want = oracle.sparse(arrays(Au), arrays(Bu), 400, symmetric=False)
     # duplicates: repeat some entries of B's rows (sorted, repeated columns)
     ip, ix, dv = arrays(B)
@@ -180,9 +182,29 @@ def test_sparse_unsorted_and_duplicate_inputs(ctx, oracle):
     try:
         assert not b.is_canonical()
         got = ctx.spgemm_host(a, b)
+        got_exact = ctx.spgemm_host(a, b, exact=True)
     finally:
         a.close(); b.close()
     assert_csr_equal(got, want, values="tol", rtol=RTOL)
+    assert_csr_equal(got_exact, want, values="bits")          # repeated columns: same-accumulator lanes of one step, in lane order
+    # unsorted AND repeated: rows of B shuffled after the duplication (the ordered path serialises the lanes that meet)
+    r = np.random.default_rng(81)
+    ix2, dv2 = Bd[1].copy(), Bd[2].copy()
+    for i in range(120):
+        s, e = ip2[i], ip2[i + 1]
+        o = r.permutation(e - s)
+        ix2[s:e], dv2[s:e] = ix2[s:e][o], dv2[s:e][o]
+    Bs = (ip2, ix2, dv2)
+    a = ctx.csr_from_scipy(signed(A, 82)); b = ctx.csr_from_arrays(120, 400, *Bs)
+    try:
+        for symmetric in (False,):
+            want = oracle.sparse(arrays(signed(A, 82)), Bs, 400, symmetric=symmetric)
+            assert_csr_equal(ctx.spgemm_host(a, b, symmetric=symmetric, exact=True), want, values="bits")
+            wd = oracle.dense(arrays(signed(A, 82)), Bs, 400, symmetric=symmetric)
+            gd = ctx.dense_host(a, b, symmetric=symmetric, exact=True)
+            assert np.array_equal(gd.view(np.int64), wd.view(np.int64))
+    finally:
+        a.close(); b.close()
 
 
 @pytest.mark.parametrize("m,k,n,da,db", CASES)
@@ -378,6 +400,9 @@ def test_unsorted_b_symmetric_and_dense_general_paths(ctx, oracle):
             assert_csr_equal(ctx.spgemm_host(a, b, symmetric=symmetric), want, values="tol", rtol=RTOL)
             wd = oracle.dense(arrays(A), arrays(B), 100, symmetric=symmetric)
             assert rel_err(ctx.dense_host(a, b, symmetric=symmetric), wd) <= RTOL
+            # round 4: bit-exact under SMM_EXACT on the general paths as well
+            assert_csr_equal(ctx.spgemm_host(a, b, symmetric=symmetric, exact=True), want, values="bits")
+            assert np.array_equal(ctx.dense_host(a, b, symmetric=symmetric, exact=True).view(np.int64), wd.view(np.int64))
     finally:
         a.close(); b.close()
 
