@@ -126,6 +126,11 @@ int  smm_ctx_tune_narrow(smm_ctx *ctx, int enable);
  * through a table of (source, length, destination) sub-runs -- which keeps the marker bitmaps small (many waves
  * per CU) and the lists 16-bit at any width.  Results do not depend on it, bit for bit. */
 int  smm_ctx_tune_symbolic(smm_ctx *ctx, int max_slab_cols);
+/* Triple product, stage 2: ring != 0 selects the ring kernel of round 4 (the tile of T as a ring of column pieces, the
+ * waves of a workgroup synchronised by progress words in LDS instead of barriers: csrc/smm_ring.hpp), 0 (default) the
+ * chunk kernel.  Results are identical (bit for bit under SMM_EXACT); the ring is the slower of the two on MI355X
+ *  and is kept as a tested alternative.  Also: env SMM_S2_RING=1 when the context is created. */
+int  smm_ctx_tune_stage2(smm_ctx *ctx, int ring);
 /* Run-time guard of SMM_EXACT.  The exact walk adds the products of one wave-instruction that fall on the same
  * accumulator in ascending lane order (the reference's order, src/sparsework.cpp:59-76) -- a property of
  * gfx950's ds_add_f64 that was measured, not one the ISA promises.  This runs a sub-millisecond kernel that

@@ -4,6 +4,7 @@
 // no device every entry point fails with SMM_ERR_NO_DEVICE.
 #include "smm_kernels.hpp"
 #include "smm_slab.hpp"
+#include "smm_ring.hpp"
 #include "../../include/smm_hip.h"
 
 #include <sys/mman.h>
@@ -69,6 +70,8 @@ struct smm_ctx {
     int piece_walk = 1;      // default mode: one piece of B per wave iteration where every piece has <= 256 entries (env SMM_PIECE_WALK=0: chunk walk)
     int sym_max_ws = 0;      // widest column slab of that walk (0 = CCS_MAX_WS); B with more columns is walked slab by slab
                              // (smm_ctx_tune_symbolic; tests set it small to reach the slab path with small matrices)
+    int s2_ring = 0;         // triple stage 2: 1 = the ring kernel of round 4 (smm_ring.hpp: correct, measured 60-63 ms against 51 at
+                             // BASELINE configs[3] -- kept as an alternative, env SMM_S2_RING=1 / smm_ctx_tune_stage2); 0 = the chunk kernel
     int s2_group = 5;        // triple stage 2: k-groups whose blocks follow each other on one XCD and share a tile of T
                              // through its L2 (env SMM_S2_GROUP; at BASELINE configs[3] 1: 58.2, 2: 56.3, 4: 60.1, 5: 54.8,
                              // 7: 54.9, 8: 58.9, 10: 54.8 ms -- powers of two lose, profiles/r2_s2_sweeps.txt)
@@ -210,6 +213,7 @@ extern "C" int smm_ctx_create(int device, void *hip_stream, smm_ctx **out)
     c->device = device;
     if (const char *e = getenv("SMM_NARROW_IDX")) c->narrow_idx = atoi(e) != 0;     // A/B switch (scripts/ab_env.sh)
     if (const char *e = getenv("SMM_S2_GROUP")) c->s2_group = std::max(1, atoi(e));
+    if (const char *e = getenv("SMM_S2_RING")) c->s2_ring = atoi(e) != 0;
     if (const char *e = getenv("SMM_SYM_WIDE")) c->sym_wide = atoi(e) != 0;
     if (const char *e = getenv("SMM_SYM_CCS")) c->sym_ccs = atoi(e) != 0;
     if (const char *e = getenv("SMM_PIECE_WALK")) c->piece_walk = atoi(e);
@@ -269,17 +273,20 @@ extern "C" void smm_ctx_destroy(smm_ctx *c)
 // tripped it is not to be trusted, and the caller gets SMM_ERR_INTERNAL -- never a hang or a fault.
 static int take_plan_error(smm_ctx *c, const char *where)
 {
-    unsigned h[2] = {0u, 0u};
+    unsigned h[16] = {0u};
     HIPCHK(hipMemcpyAsync(h, c->d_err, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (!h[0]) return SMM_OK;
+    if ((h[0] & PLAN_ERR_RING) && getenv("SMM_DEBUG"))
+        fprintf(stderr, "[smm] ring wait ran out: need %u fmin %d pmin %d fp %u step %d wave %u row block %u T_w %u\n", h[8] >> 16, (int)(short)(h[8] & 0xffff),
+                (int)h[9] >> 16, h[9] & 0xffff, (int)h[10], h[11] & 0xff, h[11] >> 8, h[12]);
     const unsigned clean[2] = {0u, 0xffffffffu};
     HIPCHK(hipMemcpyAsync(c->d_err, clean, sizeof(clean), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     static const char *names[] = {"sub-run bounds", "tail descriptor", "slab sub-run table", "start slots", "hash look-up",
-                                  "list capacity", "row counts", "list entries"};
+                                  "list capacity", "row counts", "list entries", "ring schedule / progress words of triple-product stage 2"};
     std::string what;
-    for (int b = 0; b < 8; ++b)
+    for (int b = 0; b < 9; ++b)
         if (h[0] & (1u << b)) { if (!what.empty()) what += ", "; what += names[b]; }
     return fail(SMM_ERR_INTERNAL, "%s: inconsistent plan metadata (%s; first at row %u of A) -- the result of this product is not valid; "
                                   "please report this with the operands (SMM_CHECK=1 verifies every plan)", where, what.c_str(), h[1]);
@@ -424,6 +431,13 @@ extern "C" int smm_ctx_tune_symbolic(smm_ctx *c, int max_slab_cols)
     CTX_LOCK(c);
     if (max_slab_cols < 0 || max_slab_cols > CCS_MAX_WS) return fail(SMM_ERR_INVALID, "slab width must be in [0,%d]", CCS_MAX_WS);
     c->sym_max_ws = max_slab_cols;
+    return SMM_OK;
+}
+extern "C" int smm_ctx_tune_stage2(smm_ctx *c, int ring)
+{
+    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CTX_LOCK(c);
+    c->s2_ring = ring != 0;
     return SMM_OK;
 }
 extern "C" int smm_ctx_tune_shared(smm_ctx *c, int lds_cols, int waves)
@@ -703,6 +717,9 @@ struct smm_csr {
     int ell_chunk = 0, ell_nchunks = 0; bool ell_spread = false; int64_t *ell_off = nullptr;
     short *ell_col = nullptr; double *ell_val = nullptr;
     int64_t ell_bytes = 0;                       // HBM of the ELL copy
+    // scheduled streams for the ring kernel of triple-product stage 2 (smm_ring.hpp), one per (k-group, wave)
+    int64_t *ring_off = nullptr; short *ring_col = nullptr; double *ring_val = nullptr; unsigned *ring_hdr = nullptr;
+    int ring_npieces = 0; bool ring_spread = false; int64_t ring_bytes = 0;
     int64_t derived_bytes = 0;                   // HBM of every other cached copy (tile indices, payloads, ...)
 };
 
@@ -795,6 +812,7 @@ extern "C" void smm_csr_destroy(smm_csr *m)
     for (auto &e : m->ccs) { (void)hipFree(e.cptr); (void)hipFree(e.stream); }
     (void)hipFree(m->idx16); (void)hipFree(m->idx_pad);
     (void)hipFree(m->ell_off); (void)hipFree(m->ell_col); (void)hipFree(m->ell_val);
+    (void)hipFree(m->ring_off); (void)hipFree(m->ring_col); (void)hipFree(m->ring_val); (void)hipFree(m->ring_hdr);
     delete m;
 }
 extern "C" int64_t smm_csr_rows(const smm_csr *m) { return m ? m->rows : -1; }
@@ -814,7 +832,7 @@ extern "C" int64_t smm_csr_device_bytes(const smm_csr *m)
     CTX_LOCK(m->ctx);
     int64_t own = 0;
     if (m->owned) own = (m->rows + 1) * (int64_t)sizeof(int) + (std::max<int64_t>(m->nnz, 1) + 2) * (int64_t)sizeof(int) + std::max<int64_t>(m->nnz, 1) * (int64_t)sizeof(double);
-    return own + m->derived_bytes + m->ell_bytes;
+    return own + m->derived_bytes + m->ell_bytes + m->ring_bytes;
 }
 
 // Tile geometry: nct coarse tiles of wc = nw*wf columns; fine tile t covers [t*wf,(t+1)*wf).
@@ -970,6 +988,54 @@ static int ensure_ell(smm_ctx *c, smm_csr *h, int nchunks, int chunk, bool sprea
     h->ell_chunk = chunk; h->ell_nchunks = nchunks; h->ell_spread = spread;
     h->ell_bytes = (items + 1) * (int64_t)sizeof(int64_t) + (total + WAVE) * (int64_t)(sizeof(short) + sizeof(double));
     return SMM_OK;
+}
+
+// Scheduled streams of H for the ring kernel of triple-product stage 2 (smm_ring.hpp); one copy cached per handle and
+// order (spread = default mode: a lane picks among its next 8 entries; otherwise stored order, SMM_EXACT).
+static int ring_fill(smm_ctx *c, smm_csr *h, RingBuildArgs &B, bool spread)
+{
+    if (spread) LAUNCH(c, "smm_ring_build", (smm_ring_build<8, true>), B.nkg, 1024, 0, B);
+    else LAUNCH(c, "smm_ring_build", (smm_ring_build<1, true>), B.nkg, 1024, 0, B);
+    LAUNCH_CHECK();
+    return SMM_OK;
+}
+static int ensure_ring(smm_ctx *c, smm_csr *h, bool spread)
+{
+    const int npieces = (int)((h->cols + RING_PW - 1) / RING_PW);
+    if (h->ring_val && h->ring_npieces == npieces && h->ring_spread == spread) return SMM_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(h->ring_off); (void)hipFree(h->ring_col); (void)hipFree(h->ring_val); (void)hipFree(h->ring_hdr);
+    h->ring_off = nullptr; h->ring_col = nullptr; h->ring_val = nullptr; h->ring_hdr = nullptr; h->ring_bytes = 0;
+    const int n = (int)h->rows;
+    const int nkg = (n + 16 * WAVE - 1) / (16 * WAVE);
+    const int64_t streams = (int64_t)nkg * 16;
+    int64_t *cnt = nullptr;
+    CHK(pool_get(c, (size_t)streams, &cnt));
+    if (dev_malloc(c, (void **)&h->ring_off, (size_t)(streams + 1) * sizeof(int64_t)) != hipSuccess) {
+        pool_free(c, cnt);
+        return fail(SMM_ERR_ALLOC, "hipMalloc of the ring stream index failed");
+    }
+    RingBuildArgs B{};
+    B.n = n; B.K = (int)h->cols; B.npieces = npieces; B.nkg = nkg;
+    B.h_ptr = h->ptr; B.h_idx = h->idx; B.h_val = h->val;
+    B.cnt = cnt; B.off = h->ring_off; B.err = c->d_err;
+    if (spread) LAUNCH(c, "smm_ring_build", (smm_ring_build<8, false>), nkg, 1024, 0, B);
+    else LAUNCH(c, "smm_ring_build", (smm_ring_build<1, false>), nkg, 1024, 0, B);
+    LAUNCH(c, "smm_scan", smm_scan<int64_t>, 1, 1024, 0, (int)streams, (const int64_t *)cnt, h->ring_off);
+    int64_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, h->ring_off + streams, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    pool_free(c, cnt);
+    if (dev_malloc(c, (void **)&h->ring_col, (size_t)(total + 1) * WAVE * sizeof(short)) != hipSuccess ||
+        dev_malloc(c, (void **)&h->ring_val, (size_t)(total + 1) * WAVE * sizeof(double)) != hipSuccess ||
+        dev_malloc(c, (void **)&h->ring_hdr, (size_t)(total + streams + 64) * sizeof(unsigned)) != hipSuccess)
+        return fail(SMM_ERR_ALLOC, "hipMalloc of the ring streams (%lld steps) failed", (long long)total);
+    B.col = h->ring_col; B.val = h->ring_val; B.hdr = h->ring_hdr;
+    CHK(ring_fill(c, h, B, spread));
+    h->ring_npieces = npieces; h->ring_spread = spread;
+    h->ring_bytes = (streams + 1) * (int64_t)sizeof(int64_t) + (total + 1) * WAVE * (int64_t)(sizeof(short) + sizeof(double)) +
+                    (total + streams + 64) * (int64_t)sizeof(unsigned);
+    return take_plan_error(c, "smm_ring_build");
 }
 
 static int check_pair(smm_ctx *c, smm_csr *a, smm_csr *b)
@@ -1344,6 +1410,13 @@ static int refresh_value_copies(smm_ctx *c, smm_csr *m)
         if (m->rows > 0 && m->nnz > 0)
             LAUNCH(c, "smm_slab_fill", smm_slab_fill, std::min<int64_t>((m->rows + 3) / 4, 65536), 256, 0, (int)m->rows, e.n_slabs, e.ws,
                    m->ptr, m->idx, m->val, seg, (const int *)e.soff, e.scol, e.sval);
+    }
+    if (m->ring_val) {
+        RingBuildArgs B{};
+        B.n = (int)m->rows; B.K = (int)m->cols; B.npieces = m->ring_npieces; B.nkg = (int)((m->rows + 16 * WAVE - 1) / (16 * WAVE));
+        B.h_ptr = m->ptr; B.h_idx = m->idx; B.h_val = m->val; B.off = m->ring_off; B.err = c->d_err;
+        B.col = m->ring_col; B.val = m->ring_val; B.hdr = m->ring_hdr;
+        CHK(ring_fill(c, m, B, m->ring_spread));
     }
     if (m->ell_val) {
         Geom gh; gh.nw = 1; gh.nct = m->ell_nchunks; gh.wf = m->ell_chunk; gh.wc = m->ell_chunk; gh.n_ft = m->ell_nchunks;
@@ -2286,6 +2359,45 @@ extern "C" int smm_triple_product(smm_ctx *c, smm_csr *h, smm_csr *q, int flags,
 #endif
     constexpr int NW = SMM_S2_NW;          // waves per workgroup = 64-row slices of H per k-group
     constexpr int R = 16;
+    if (c->s2_ring && NW == 16 && (K + RING_PW - 1) / RING_PW < 65535) {
+        // round 4: ring of column pieces, progress words instead of barriers (smm_ring.hpp)
+        const bool exact_r = (flags & SMM_EXACT) != 0;
+        rc = ensure_ring(c, h, !exact_r);
+        if (rc != SMM_OK) { pool_free(c, T); return rc; }
+        RingArgs A{};
+        A.n = (int)n; A.K = (int)K; A.npieces = h->ring_npieces; A.nslices = (int)((n + WAVE - 1) / WAVE);
+        A.nib = (int)((nr + R - 1) / R);
+        A.row_begin = row_begin; A.row_end = row_end; A.full = full ? 1 : 0;
+        A.off = h->ring_off; A.col = h->ring_col; A.val = h->ring_val; A.hdr = h->ring_hdr;
+        A.T = T; A.C = d_c; A.ldc = n; A.err = c->d_err;
+        const int64_t nkg = (n + 16 * WAVE - 1) / (16 * WAVE);
+        A.nkg = (int)nkg;
+        A.gk = (int)std::min<int64_t>(std::max(c->s2_group, 1), nkg);
+        const int64_t grid2 = ((nkg + A.gk - 1) / A.gk) * A.gk * (((int64_t)A.nib + 7) / 8) * 8;
+        if (grid2 > 0x7fffffff) { pool_free(c, T); return fail(SMM_ERR_INVALID, "triple product too large for one launch"); }
+        const size_t lds = (size_t)RING_NB * RING_PW * (R + 2) * sizeof(double);
+        auto kern = exact_r ? smm_triple_stage2_ring<R, 16, false> : smm_triple_stage2_ring<R, 16, true>;
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { pool_free(c, T); return fail(SMM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e)); }
+        LAUNCH(c, "smm_triple_stage2", kern, grid2, 16 * 64, lds, A);
+        if (full) LAUNCH(c, "smm_triple_mirror", smm_triple_mirror, (n * n + 255) / 256, 256, 0, (int)n, d_c, n);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // T returns to the pool below
+        pool_free(c, T);
+        if (e != hipSuccess) return fail(SMM_ERR_HIP, "triple product: %s", hipGetErrorString(e));
+#ifdef SMM_RING_STAMPS
+        {
+            unsigned long long st[6];
+            (void)hipMemcpy(st, c->d_err + 4, sizeof(st), hipMemcpyDeviceToHost);
+            (void)hipMemset(c->d_err + 4, 0, sizeof(st));
+            fprintf(stderr, "[SMM_RING_STAMPS] wave-cycles %.4g: waiting for pieces %.1f%%  tail (owed shares) %.1f%%;  slow-path entries %.3g, spins %.3g, steps %.3g\n",
+                    (double)st[0], 100.0 * st[1] / st[0], 100.0 * st[2] / st[0], (double)st[3], (double)st[4], (double)st[5]);
+        }
+#endif
+        CHK(take_plan_error(c, "smm_triple_product"));              // (a bounded wait of the ring protocol ran out: never expected)
+        if (mirror) CHK(mirror_upper(c, n, d_c, n));
+        return SMM_OK;
+    }
     constexpr int chunk_cap = NW * 64;     // one tile column per thread; [chunk][R+2] f64 = 144 KB of LDS at 16 waves
     const int nchunks = (int)((K + chunk_cap - 1) / chunk_cap);
     const int chunk = (int)((K + nchunks - 1) / nchunks);

@@ -85,6 +85,10 @@ class Context:
         """Widest column slab of the symbolic walk (0 = default 63456); a wider B is walked slab by slab."""
         check(self.lib, self.lib.smm_ctx_tune_symbolic(self.handle, int(max_slab_cols)))
 
+    def tune_stage2(self, ring=False):
+        """Triple product, stage 2: the ring kernel of round 4 (True) or the chunk kernel (False, default)."""
+        check(self.lib, self.lib.smm_ctx_tune_stage2(self.handle, 1 if ring else 0))
+
     def exact_selftest(self, inject_fault=False):
         """Run the SMM_EXACT guard now (every context runs it by itself before its first exact product):
         raises SmmError (code SMM_ERR_UNSUPPORTED) where the device does not add same-address lanes of one
