@@ -39,7 +39,8 @@ def test_ring_kernel_matches_oracle(ring, oracle, n, k, dh, dq, full, exact):
     try:
         ring.timing(True); ring.timing_reset()
         got = ring.triple_host(h, q, full=bool(full), exact=exact)
-        assert ring.kernel_time("smm_ring_build")[1] >= 2          # the schedule was built (count + fill passes): the ring path ran
+        if H.nnz and Q.nnz:                                    # (a zero operand returns zeros without any kernel)
+            assert ring.kernel_time("smm_ring_build")[1] >= 2      # the schedule was built (count + fill passes): the ring path ran
         ring.timing(False)
         # new values on the same pattern: the scheduled streams are re-filled in place
         H2 = signed(H, 7)
