@@ -300,7 +300,7 @@ def run_config(cfg, args, env, steps, warmup, cpu_leg):
             # (rocprofv3 cannot run inside the bench; profiles/ says how it was taken)
             traffic, traffic_src = None, None
             ran = sorted(k for k in NUMERIC_KERNELS if per_launch(k) > 0)
-            for name in ("traffic_r3.json", "traffic_r2.json", "traffic_r1.json"):
+            for name in ("traffic_r4.json", "traffic_r3.json", "traffic_r2.json", "traffic_r1.json"):
                 try:
                     tj = json.load(open(os.path.join(ROOT, "profiles", name)))
                     if (m, n, d) == (50000, 50000, 0.01) and not args.exact and not (args.lds_cols or args.waves or args.slab) \
