@@ -70,6 +70,7 @@ struct smm_ctx {
     int piece_walk = 1;      // default mode: one piece of B per wave iteration where every piece has <= 256 entries (env SMM_PIECE_WALK=0: chunk walk)
     int sym_max_ws = 0;      // widest column slab of that walk (0 = CCS_MAX_WS); B with more columns is walked slab by slab
                              // (smm_ctx_tune_symbolic; tests set it small to reach the slab path with small matrices)
+    int numeric_persist = 1; // smm_numeric: persistent workgroups fed by a unit counter (env SMM_NUMERIC_PERSIST: 0 never, 1 CSR output without triangle, 2 always)
     int s2_ring = 0;         // triple stage 2: 1 = the ring kernel of round 4 (smm_ring.hpp: correct, measured 60-63 ms against 51 at
                              // BASELINE configs[3] -- kept as an alternative, env SMM_S2_RING=1 / smm_ctx_tune_stage2); 0 = the chunk kernel
     int s2_group = 5;        // triple stage 2: k-groups whose blocks follow each other on one XCD and share a tile of T
@@ -214,6 +215,7 @@ extern "C" int smm_ctx_create(int device, void *hip_stream, smm_ctx **out)
     if (const char *e = getenv("SMM_NARROW_IDX")) c->narrow_idx = atoi(e) != 0;     // A/B switch (scripts/ab_env.sh)
     if (const char *e = getenv("SMM_S2_GROUP")) c->s2_group = std::max(1, atoi(e));
     if (const char *e = getenv("SMM_S2_RING")) c->s2_ring = atoi(e) != 0;
+    if (const char *e = getenv("SMM_NUMERIC_PERSIST")) c->numeric_persist = atoi(e);
     if (const char *e = getenv("SMM_SYM_WIDE")) c->sym_wide = atoi(e) != 0;
     if (const char *e = getenv("SMM_SYM_CCS")) c->sym_ccs = atoi(e) != 0;
     if (const char *e = getenv("SMM_PIECE_WALK")) c->piece_walk = atoi(e);
@@ -1086,8 +1088,21 @@ static int launch_numeric_t(smm_ctx *c, NumericArgs &args)
     auto kern = smm_numeric<OUT, SYM, NW, EXACT, SCR, L16, SLAB>;
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int64_t grid = (int64_t)args.m * args.nct;
+    int64_t grid = (int64_t)args.m * args.nct;
     if (grid > 0x7fffffff) return fail(SMM_ERR_INVALID, "too many (row, tile) units for one launch");
+    args.unit_counter = nullptr; args.n_units = (unsigned)grid;
+    // Persistent workgroups where every unit is real work (CSR output, no triangle): -0.3 ms at configs[1], -0.9 ms on a
+    // configs[4] share, -0.6 ms under SMM_EXACT.  Dense output measured neutral (configs[2]) and, with the trivial units
+    // below the diagonal, slower (stage 1 of configs[3]: 19.2 against 18.4 ms) -- those keep one unit per workgroup
+    // unless SMM_NUMERIC_PERSIST=2 (profiles/r4_numeric_persist.txt).
+    const bool persist = c->numeric_persist == 2 || (c->numeric_persist == 1 && OUT == OUT_SPARSE && !SYM);
+    if (persist && grid > c->n_cu) {
+        // as many workgroups as are resident at once (more would only find the counter spent)
+        const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(32 / NW, (int64_t)(160 * 1024) / (int64_t)(lds + 64)));
+        args.unit_counter = (unsigned *)((char *)c->d_flags + 220);
+        HIPCHK(hipMemsetAsync(args.unit_counter, 0, sizeof(unsigned), c->stream));
+        grid = std::min<int64_t>(grid, per_cu * c->n_cu);
+    }
 #ifdef SMM_STAMPS
     unsigned long long *d_st = nullptr;
     CHK(pool_get(c, 4, &d_st));

@@ -1316,6 +1316,7 @@ struct NumericArgs {
     const uint2 *runs2; int n_slabs, tps, ws, mtot; int64_t nnzA;
     unsigned long long *stamps;     // diagnostic builds (-DSMM_STAMPS) only: 4 phase totals
     unsigned *err;                  // the context's error word (PLAN_ERR_*)
+    unsigned *unit_counter; unsigned n_units;   // persistent workgroups (NULL: one unit per workgroup)
     // dense output
     double *c_dense; int64_t ldc;
 };
@@ -1689,11 +1690,10 @@ constexpr int EPI_UNROLL = SMM_EPI_UNROLL;
 // L16: the ordered lists are uint16 (a template parameter, not a run-time switch: a branch inside the epilogue's
 // "all loads first" loop made every load wait for the one before it -- 30 -> 37 ms).
 template <int OUT, bool SYM, int NW, bool EXACT, bool SCR = false, bool L16 = false, bool SLAB = false>
-__global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
+__device__ __forceinline__ void smm_numeric_unit(const NumericArgs &A, double *__restrict__ acc, const unsigned unit_index)
 {
     static_assert(!SCR || OUT == OUT_SPARSE, "the scratch source feeds the CSR emission only");
     static_assert(!SLAB || (OUT == OUT_SPARSE && L16 && !SCR), "slab-local lists: CSR output, 16-bit lists");
-    extern __shared__ double acc[];
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     constexpr int NT = NW * 64;
@@ -1708,8 +1708,8 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
 #define SMM_MARK()
 #define SMM_LAP(var)
 #endif
-    const int tc = blockIdx.x / A.m;            // tile-major: concurrent units share B's slab
-    const int ridx = blockIdx.x - tc * A.m;
+    const int tc = (int)(unit_index / (unsigned)A.m);     // tile-major: concurrent units share B's slab
+    const int ridx = (int)(unit_index - (unsigned)tc * (unsigned)A.m);
     const int row = A.rowlist ? A.rowlist[ridx] : ridx;
     const int a0 = A.a_ptr[row], a1 = A.a_ptr[row + 1];
     const int64_t gi = row + A.row_offset;
@@ -1886,6 +1886,28 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
 #endif
 #undef SMM_MARK
 #undef SMM_LAP
+}
+
+// The kernel: one (row, tile) unit per workgroup (A.unit_counter == NULL: unit = blockIdx.x), or -- round 4 -- PERSISTENT
+// workgroups that take units from a global counter, in order (tile-major order is kept: the counter only ever grows), until
+// it passes the last unit: a resident workgroup never gives its CU and its 133 KB of LDS back between two units.
+template <int OUT, bool SYM, int NW, bool EXACT, bool SCR = false, bool L16 = false, bool SLAB = false>
+__global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
+{
+    extern __shared__ double acc[];
+    if (!A.unit_counter) {
+        smm_numeric_unit<OUT, SYM, NW, EXACT, SCR, L16, SLAB>(A, acc, blockIdx.x);
+        return;
+    }
+    __shared__ unsigned s_unit;
+    for (;;) {
+        if (threadIdx.x == 0) s_unit = atomicAdd(A.unit_counter, 1u);
+        __syncthreads();
+        const unsigned unit = s_unit;
+        if (unit >= A.n_units) break;                   // (every workgroup leaves: the counter passes the last unit for each of them)
+        smm_numeric_unit<OUT, SYM, NW, EXACT, SCR, L16, SLAB>(A, acc, unit);
+        __syncthreads();                                // nobody reads the tile or s_unit any more
+    }
 }
 
 // ---------------------------------------------------------------------------------------
