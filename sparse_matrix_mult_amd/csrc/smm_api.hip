@@ -1095,7 +1095,7 @@ static int launch_numeric_t(smm_ctx *c, NumericArgs &args)
     // configs[4] share, -0.6 ms under SMM_EXACT.  Dense output measured neutral (configs[2]) and, with the trivial units
     // below the diagonal, slower (stage 1 of configs[3]: 19.2 against 18.4 ms) -- those keep one unit per workgroup
     // unless SMM_NUMERIC_PERSIST=2 (profiles/r4_numeric_persist.txt).
-    const bool persist = c->numeric_persist == 2 || (c->numeric_persist == 1 && OUT == OUT_SPARSE && !SYM);
+    const bool persist = c->numeric_persist == 2 || (c->numeric_persist == 1 && OUT == OUT_SPARSE);
     if (persist && grid > c->n_cu) {
         // as many workgroups as are resident at once (more would only find the counter spent)
         const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(32 / NW, (int64_t)(160 * 1024) / (int64_t)(lds + 64)));
@@ -1169,6 +1169,7 @@ struct smm_plan {
     int *d_scnt = nullptr;         // n_slabs x m
     unsigned *d_dst0 = nullptr;    // nnz(A)
     uint2 *d_runs2 = nullptr;      // nct x nnz(A)
+    unsigned char *d_tflag = nullptr;   // nct x m: which (tile, row) units hold entries of C
     const int *seg = nullptr;      // B's tile index and tile-local columns for geometry g (owned by b)
     const short *loc = nullptr;
     smm_csr::PackCache pack{0, 0, nullptr, nullptr, 0};   // default mode: packed payload of B for geometry g
@@ -1191,7 +1192,7 @@ extern "C" void smm_plan_destroy(smm_plan *p)
     (void)hipStreamSynchronize(c->stream);
     pool_free(c, p->d_ub_off); pool_free(c, p->d_tmp); pool_free(c, p->d_P); pool_free(c, p->d_runs);
     pool_free(c, p->d_rowcnt); pool_free(c, p->d_cptr); pool_free(c, p->d_lists); pool_free(c, p->d_tail);
-    pool_free(c, p->d_scnt); pool_free(c, p->d_dst0); pool_free(c, p->d_runs2);
+    pool_free(c, p->d_scnt); pool_free(c, p->d_dst0); pool_free(c, p->d_runs2); pool_free(c, p->d_tflag);
     delete p;
 }
 extern "C" int64_t smm_plan_nnz(const smm_plan *p) { return p ? p->nnz : -1; }
@@ -1202,7 +1203,7 @@ extern "C" int64_t smm_plan_device_bytes(const smm_plan *p)
     CTX_LOCK(c);
     int64_t total = 0;
     const void *blocks[] = {p->d_ub_off, p->d_tmp, p->d_P, p->d_runs, p->d_rowcnt, p->d_cptr, p->d_lists, p->d_tail,
-                            p->d_scnt, p->d_dst0, p->d_runs2};
+                            p->d_scnt, p->d_dst0, p->d_runs2, p->d_tflag};
     for (const void *b : blocks) {
         auto it = c->live.find((void *)b);
         if (b && it != c->live.end()) total += (int64_t)it->second;
@@ -1822,10 +1823,11 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
                 }
                 PCHK(pool_get(c, (size_t)a->nnz, &p->d_dst0));
                 PCHK(pool_get(c, (size_t)a->nnz * p->g.nct, &p->d_runs2));
+                PCHK(pool_get(c, (size_t)m * p->g.nct, &p->d_tflag));
                 const int nd = p->n_bin[2];
                 LAUNCH(c, "smm_runs", smm_runs_slab, std::min<int64_t>((nd + 3) / 4, 65536), 256, 0, nd, (int)m, ns, tps, p->g.nct, p->g.wc,
                        (int64_t)a->nnz, (const int *)(p->d_lists + 2 * m), a->ptr, (const int64_t *)p->d_ub_off, (const int *)p->d_scnt,
-                       (const unsigned *)p->d_P, (const unsigned short *)p->d_tmp, p->d_dst0, p->d_runs2, c->d_err);
+                       (const unsigned *)p->d_P, (const unsigned short *)p->d_tmp, p->d_dst0, p->d_runs2, p->d_tflag, c->d_err);
                 hipError_t e = hipGetLastError();
                 if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "smm_runs_slab: %s", hipGetErrorString(e)); }
             }
@@ -2031,7 +2033,7 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
         A.rowsB = (int)p->b->rows;
         A.c_ptr = p->d_cptr; A.c_idx = d_c_indices; A.c_val = d_c_data;
         A.ub_off = p->d_ub_off; A.tmp_idx = p->d_tmp; A.list16 = p->list16 ? 1 : 0; A.runs = p->d_runs; A.tail = p->d_tail;
-        A.runs2 = p->d_runs2; A.n_slabs = p->n_slabs; A.tps = p->tps; A.ws = p->ws; A.mtot = (int)m; A.nnzA = p->a->nnz;
+        A.runs2 = p->d_runs2; A.tflag = p->d_tflag; A.n_slabs = p->n_slabs; A.tps = p->tps; A.ws = p->ws; A.mtot = (int)m; A.nnzA = p->a->nnz;
         if (p->use_slab) {
             // values in column order into a dense scratch (one row per row of the bin), then the emission
             double *scratch = nullptr;

@@ -1157,10 +1157,12 @@ __global__ __launch_bounds__(256) void smm_runs_slab(int nrows, int m, int n_sla
                                                      const int *__restrict__ rowlist, const int *__restrict__ a_ptr,
                                                      const int64_t *__restrict__ list_off, const int *__restrict__ scnt,
                                                      const unsigned *__restrict__ P, const unsigned short *__restrict__ tmp,
-                                                     unsigned *__restrict__ dst0, uint2 *__restrict__ runs2, unsigned *__restrict__ err)
+                                                     unsigned *__restrict__ dst0, uint2 *__restrict__ runs2,
+                                                     unsigned char *__restrict__ tflag, unsigned *__restrict__ err)
 {
     __shared__ int win_all[4][RUNS_WIN];
     constexpr int NV = RUNS_WIN / WAVE;
+    constexpr int TPS_MAX = 8;                       // tiles per slab (smm_api.hip: tps <= 8)
     const int lane = lane_id();
     const int wpb = blockDim.x / WAVE;
     int *win = win_all[threadIdx.x >> 6];
@@ -1251,6 +1253,7 @@ __global__ __launch_bounds__(256) void smm_runs_slab(int nrows, int m, int n_sla
             }
             // the table entries (the starts written above are read back by the lane that wrote them)
             __threadfence_block();
+            unsigned any = 0;                                   // bit tt: this lane saw an entry of tile t0 + tt
             for (int eb = a0; eb < a1; eb += WAVE) {
                 const int e = eb + lane;
                 if (e >= a1) continue;
@@ -1265,8 +1268,14 @@ __global__ __launch_bounds__(256) void smm_runs_slab(int nrows, int m, int n_sla
                 for (int tt = 0; tt < tsl; ++tt) {
                     const unsigned en = tt + 1 < tsl ? r[(size_t)(tt + 1) * nnzA].x : p1;
                     r[(size_t)tt * nnzA] = make_uint2(st | ((en - st) << 16), base + (st - p0));
+                    any |= (en != st ? 1u : 0u) << tt;
                     st = en;
                 }
+            }
+            // which (tile, row) units have anything to emit: the numeric phase skips the others before it touches its tile
+            for (int tt = 0; tt < tsl && tt < TPS_MAX; ++tt) {
+                const bool some = __ballot((any >> tt) & 1u) != 0ull;
+                if (lane == 0) tflag[(size_t)(t0 + tt) * m + row] = some ? 1 : 0;
             }
         }
     }
@@ -1314,6 +1323,7 @@ struct NumericArgs {
     const int *rowlist;             // rows handled by this launch (NULL = all m rows)
     // column slabs (smm_runs_slab): slab-local lists, ub_off indexed [slab * mtot + row]
     const uint2 *runs2; int n_slabs, tps, ws, mtot; int64_t nnzA;
+    const unsigned char *tflag;     // [nct][mtot]: 0 = the (tile, row) unit holds no entry of C (smm_runs_slab)
     unsigned long long *stamps;     // diagnostic builds (-DSMM_STAMPS) only: 4 phase totals
     unsigned *err;                  // the context's error word (PLAN_ERR_*)
     unsigned *unit_counter; unsigned n_units;   // persistent workgroups (NULL: one unit per workgroup)
@@ -1711,6 +1721,8 @@ __device__ __forceinline__ void smm_numeric_unit(const NumericArgs &A, double *_
     const int tc = (int)(unit_index / (unsigned)A.m);     // tile-major: concurrent units share B's slab
     const int ridx = (int)(unit_index - (unsigned)tc * (unsigned)A.m);
     const int row = A.rowlist ? A.rowlist[ridx] : ridx;
+    // (slab-local lists: operands with structure -- a band, blocks -- leave most tiles of a wide row empty)
+    if constexpr (SLAB) { if (!A.tflag[(size_t)tc * A.mtot + row]) return; }
     const int a0 = A.a_ptr[row], a1 = A.a_ptr[row + 1];
     const int64_t gi = row + A.row_offset;
     const int lo_c = tc * A.wc;
@@ -1899,14 +1911,27 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
         smm_numeric_unit<OUT, SYM, NW, EXACT, SCR, L16, SLAB>(A, acc, blockIdx.x);
         return;
     }
-    __shared__ unsigned s_unit;
+    // Units are taken in batches of up to 8 (one counter round trip per batch: a unit that turns out to be empty -- a tile
+    // left of the diagonal, an empty tile of a banded row -- costs a test, not a round trip), shrinking to 1 towards the
+    // end of the launch so that the last workgroups finish together.
+    __shared__ unsigned s_unit[2];
     for (;;) {
-        if (threadIdx.x == 0) s_unit = atomicAdd(A.unit_counter, 1u);
+        if (threadIdx.x == 0) {
+            const unsigned seen = __hip_atomic_load(A.unit_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned b = (seen < A.n_units ? A.n_units - seen : 0u) / (4u * gridDim.x);
+            b = b < 1u ? 1u : (b > 8u ? 8u : b);
+            s_unit[0] = atomicAdd(A.unit_counter, b);
+            s_unit[1] = b;
+        }
         __syncthreads();
-        const unsigned unit = s_unit;
-        if (unit >= A.n_units) break;                   // (every workgroup leaves: the counter passes the last unit for each of them)
-        smm_numeric_unit<OUT, SYM, NW, EXACT, SCR, L16, SLAB>(A, acc, unit);
-        __syncthreads();                                // nobody reads the tile or s_unit any more
+        const unsigned u0 = s_unit[0];
+        unsigned u1 = u0 + s_unit[1];
+        if (u0 >= A.n_units) break;                     // (every workgroup leaves: the counter passes the last unit for each of them)
+        u1 = u1 < A.n_units ? u1 : A.n_units;
+        for (unsigned unit = u0; unit < u1; ++unit) {
+            smm_numeric_unit<OUT, SYM, NW, EXACT, SCR, L16, SLAB>(A, acc, unit);
+            __syncthreads();                            // nobody reads the tile or s_unit any more
+        }
     }
 }
 
