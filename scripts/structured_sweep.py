@@ -17,7 +17,7 @@ import torch  # noqa: E402
 from sparse_matrix_mult_amd import engine  # noqa: E402
 
 KERNELS = ("smm_validate", "smm_segptr", "smm_idx16", "smm_pack_fill", "smm_ccs_fill", "smm_row_work", "smm_scan", "smm_bin_rows",
-           "smm_symbolic", "smm_symbolic_hash", "smm_copy_lists", "smm_runs", "smm_numeric", "smm_numeric_hash", "smm_numeric_general",
+           "smm_symbolic", "smm_symbolic_hash", "smm_symbolic_tiny", "smm_numeric_tiny", "smm_copy_lists", "smm_runs", "smm_numeric", "smm_numeric_hash", "smm_numeric_general",
            "smm_dense_slab", "smm_emit", "smm_plan_check")
 
 
@@ -47,6 +47,13 @@ def arrow(n, rng):
     return A.tocsr()
 
 
+def two_per_row(n, rng):
+    c1 = rng.integers(0, n, size=n, dtype=np.int64)
+    c2 = (c1 + 1 + rng.integers(0, n - 1, size=n, dtype=np.int64)) % n          # != c1
+    cols = np.stack([np.minimum(c1, c2), np.maximum(c1, c2)], axis=1).reshape(-1).astype(np.int32)
+    return sp.csr_matrix((rng.standard_normal(2 * n), cols, np.arange(0, 2 * n + 1, 2, dtype=np.int64)), shape=(n, n))
+
+
 def families(rng):
     yield "uniform 20k d=0.01", lambda: (sp.random(20000, 20000, 0.01, "csr", random_state=rng),) * 2
     yield "banded n=2M half-width 8", lambda: (banded(2_000_000, 8, rng),) * 2
@@ -57,6 +64,7 @@ def families(rng):
     yield "tall-skinny 1M x 2000 d=0.005 times 2000 x 2000 d=0.05", lambda: (
         sp.random(1_000_000, 2000, 0.005, "csr", random_state=rng), sp.random(2000, 2000, 0.05, "csr", random_state=rng))
     yield "arrow n=30k (dense first row and column)", lambda: (arrow(30000, rng),) * 2
+    yield "30M rows, 2 per row", lambda: (two_per_row(30_000_000, rng),) * 2
 
 
 def main():

@@ -82,6 +82,7 @@ struct smm_ctx {
     int waves_shared = 16;
     int hash_small = 256;    // rows of C with <= hash_small nonzeros: one wave per row, LDS hash (0 = off)
     int hash_medium = 2048;  // ... <= hash_medium: one workgroup per row, LDS hash; above: dense LDS tiles
+    int tiny_max = TINY_G;   // rows with <= 16 products from <= 16 entries of A: smm_*_tiny, four rows per wave (env SMM_TINY=0: off)
     // row block x column slab kernels (smm_slab.hpp): mode 0 = where they pay, 1 = never, 2 = wherever
     // they can run; ws = slab width (0 = sized so that one slab of B is ~3 MB, L2-resident);
     // rows per wave 2 or 4 (8 waves per workgroup: 16 or 32 rows per block)
@@ -216,6 +217,7 @@ extern "C" int smm_ctx_create(int device, void *hip_stream, smm_ctx **out)
     if (const char *e = getenv("SMM_S2_GROUP")) c->s2_group = std::max(1, atoi(e));
     if (const char *e = getenv("SMM_S2_RING")) c->s2_ring = atoi(e) != 0;
     if (const char *e = getenv("SMM_NUMERIC_PERSIST")) c->numeric_persist = atoi(e);
+    if (const char *e = getenv("SMM_TINY")) c->tiny_max = atoi(e) != 0 ? TINY_G : 0;
     if (const char *e = getenv("SMM_SYM_WIDE")) c->sym_wide = atoi(e) != 0;
     if (const char *e = getenv("SMM_SYM_CCS")) c->sym_ccs = atoi(e) != 0;
     if (const char *e = getenv("SMM_PIECE_WALK")) c->piece_walk = atoi(e);
@@ -1178,8 +1180,8 @@ struct smm_plan {
     smm_csr::SlabCache slab{0, 0, nullptr, nullptr, nullptr};
     int *d_rowcnt = nullptr;       // m
     int64_t total_cap = 0;         // sum of the list capacities (= d_ub_off's last entry)
-    int *d_lists = nullptr;        // 3 x m: rows of the small / medium / dense bins
-    int n_bin[3] = {0, 0, 0};
+    int *d_lists = nullptr;        // 4 x m: rows of the small / medium / dense / tiny bins
+    int n_bin[4] = {0, 0, 0, 0};
     int64_t *d_cptr = nullptr;     // m+1
 };
 
@@ -1690,8 +1692,12 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     PCHK(pool_get(c, (size_t)m, &d_ub));
     PCHK(pool_get(c, (size_t)m + 1, &p->d_ub_off));
     const int wgrid = (int)std::min<int64_t>((m + 3) / 4, 16384);
-    LAUNCH(c, "smm_row_work", smm_row_work, wgrid, 256, 0, (int)m, (int)p->ncols, p->row_offset, sym ? 1 : 0, a->ptr,
-           a->idx, b->ptr, d_prod, d_ub);
+    if (a->nnz <= 8 * m)         // short rows on average: a row per lane instead of a row per wave
+        LAUNCH(c, "smm_row_work", smm_row_work_short, (int)std::min<int64_t>((m + 255) / 256, 65536), 256, 0, (int)m, (int)p->ncols,
+               p->row_offset, sym ? 1 : 0, a->ptr, a->idx, b->ptr, d_prod, d_ub);
+    else
+        LAUNCH(c, "smm_row_work", smm_row_work, wgrid, 256, 0, (int)m, (int)p->ncols, p->row_offset, sym ? 1 : 0, a->ptr,
+               a->idx, b->ptr, d_prod, d_ub);
     PCHK(scan_launch<int64_t>(c, m, d_ub, p->d_ub_off));
     // The marker of the symbolic phase is a bitmap of B's columns (ncols/8 bytes per wave, in LDS when
     // it fits): at 50 000 columns 24 waves fit a CU, at 1e6 columns one.  Rows with few products --
@@ -1704,25 +1710,28 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     constexpr int HS0 = 512, HS1 = 4096;
     const int hmax0 = (!safe && bm_bytes > HS0 * 4) ? HS0 / 2 : 0;
     const int hmax1 = (!safe && bm_bytes > HS1 * 4) ? HS1 / 2 : hmax0;
-    int sbin[3] = {0, 0, (int)m};
+    // ... and TINY rows (<= 16 products from <= 16 entries of A, whatever B looks like) go four to a wave (smm_symbolic_tiny)
+    const int tiny_max = c->tiny_max;
+    const bool binned = hmax1 > 0 || tiny_max > 0;
+    int sbin[4] = {0, 0, (int)m, 0};
     int *d_slists = nullptr;
     int *d_scounts = (int *)((char *)c->d_flags + 224);
-    if (hmax1 > 0) {
-        PCHK(pool_get(c, (size_t)3 * m, &d_slists));
-        hipError_t e = hipMemsetAsync(d_scounts, 0, 3 * sizeof(int), c->stream);
+    if (binned) {
+        PCHK(pool_get(c, (size_t)4 * m, &d_slists));
+        hipError_t e = hipMemsetAsync(d_scounts, 0, 4 * sizeof(int), c->stream);
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "memset: %s", hipGetErrorString(e)); }
         LAUNCH(c, "smm_bin_rows", smm_bin_rows<int64_t>, std::min<int64_t>((m + 1023) / 1024, 2048), 1024, 0, (int)m, hmax0, hmax1,
-               (const int64_t *)d_ub, d_slists, d_scounts);
+               (const int64_t *)d_ub, d_slists, d_scounts, tiny_max, (const int64_t *)d_prod, a->ptr);
     }
     int64_t total_ub = 0;
     {
         hipError_t e = hipMemcpyAsync(&total_ub, p->d_ub_off + m, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess && hmax1 > 0)
-            e = hipMemcpyAsync(sbin, d_scounts, 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && binned)
+            e = hipMemcpyAsync(sbin, d_scounts, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "row work: %s", hipGetErrorString(e)); }
     }
-    pool_free(c, d_prod); pool_free(c, d_ub);
+    pool_free(c, d_ub);             // (d_prod lives on: the numeric binning at the end applies the same tiny-row predicate)
     // Column slabs (round 3): B wider than one slab of the chunked stream (or than smm_ctx_tune_symbolic allows), sorted,
     // without repeated columns, and most rows beyond the hash-set classes -> every (slab, row) is walked on its own.
     {
@@ -1731,6 +1740,7 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         const bool dominant = c->sym_max_ws > 0 || hmax1 == 0 || 2 * (int64_t)sbin[2] >= m;
         if (c->sym_ccs && c->narrow_idx && wide && dominant && !safe && p->b_sorted && c->slab_mode != 2) {
             if (d_slists) pool_free(c, d_slists);
+            pool_free(c, d_prod);
             // tiles per slab: as many as fit the slab limit (<= 8), but not so many that the marker bitmap leaves fewer
             // than 28 waves per CU (configs[4] share: 3 tiles = 60 000 columns = 21 waves 12.4 ms, 2 tiles = 31 waves 11.7 ms)
             int tps = std::max(1, std::min(8, ws_cap / p->g.wc));
@@ -1805,12 +1815,12 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
             }
             if (p->nnz > 0) {
                 // every non-empty row goes to the tile kernel (the hash kernels read one list per row)
-                PCHK(pool_get(c, (size_t)3 * m, &p->d_lists));
+                PCHK(pool_get(c, (size_t)4 * m, &p->d_lists));
                 int *d_counts = (int *)((char *)c->d_flags + 192);
-                hipError_t e = hipMemsetAsync(d_counts, 0, 3 * sizeof(int), c->stream);
+                hipError_t e = hipMemsetAsync(d_counts, 0, 4 * sizeof(int), c->stream);
                 LAUNCH(c, "smm_bin_rows", smm_bin_rows<int>, std::min<int64_t>((m + 1023) / 1024, 2048), 1024, 0, (int)m, 0, 0,
                        (const int *)p->d_rowcnt, p->d_lists, d_counts);
-                if (e == hipSuccess) e = hipMemcpyAsync(p->n_bin, d_counts, 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(p->n_bin, d_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
                 if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "row binning: %s", hipGetErrorString(e)); }
             }
@@ -1847,7 +1857,7 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     }
     PCHK(pool_get(c, (size_t)a->nnz, &p->d_P));
     PCHK(pool_get(c, (size_t)m, &p->d_rowcnt));
-    if (hmax1 > 0) {            // rows without products are in no bin: their count stays 0
+    if (binned) {               // rows without products are in no bin: their count stays 0
         hipError_t e = hipMemsetAsync(p->d_rowcnt, 0, (size_t)m * sizeof(int), c->stream);
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "memset: %s", hipGetErrorString(e)); }
     }
@@ -1857,6 +1867,19 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     {
         hipError_t e = hipMemsetAsync(d_rowctr, 0, 3 * sizeof(int), c->stream);
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "memset: %s", hipGetErrorString(e)); }
+    }
+    // tiny rows: four to a wave, no marker at all
+    if (sbin[3] > 0) {
+        const int tgrid = (int)std::min<int64_t>(((int64_t)sbin[3] + 15) / 16, (int64_t)c->n_cu * 32);
+        const int *rows3 = d_slists + (size_t)3 * m;
+#define TINY_CASE(S, IT)                                                                                                        \
+        LAUNCH(c, "smm_symbolic_tiny", (smm_symbolic_tiny<S, IT>), tgrid, 256, 0, sbin[3], rows3, p->row_offset, a->ptr, a->idx,  \
+               b->ptr, b->idx, (const int64_t *)p->d_ub_off, (IT *)p->d_tmp, p->d_P, p->d_rowcnt);
+        if (p->list16) { if (sym) { TINY_CASE(true, unsigned short) } else { TINY_CASE(false, unsigned short) } }
+        else           { if (sym) { TINY_CASE(true, int) } else { TINY_CASE(false, int) } }
+#undef TINY_CASE
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "smm_symbolic_tiny: %s", hipGetErrorString(e)); }
     }
     // hash classes: one wave per row, four rows per workgroup
     for (int cls = 0; cls < 2; ++cls) {
@@ -1868,9 +1891,9 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     }
     // bitmap kernels for the rest: one wave per row; waves per workgroup are chosen so that as many
     // waves as possible fit a CU's 160 KB
-    const int64_t nbm = hmax1 > 0 ? sbin[2] : m;
-    const int *bm_rows = hmax1 > 0 ? d_slists + (size_t)2 * m : nullptr;
-    const int *bm_count = hmax1 > 0 ? d_scounts + 2 : nullptr;
+    const int64_t nbm = binned ? sbin[2] : m;
+    const int *bm_rows = binned ? d_slists + (size_t)2 * m : nullptr;
+    const int *bm_count = binned ? d_scounts + 2 : nullptr;
     int wpb = 4, waves_per_cu = 8;
     if (ldsbm) {
         int best = 0;
@@ -1928,15 +1951,17 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     }
     if (gbm) pool_free(c, gbm);
     if (d_slists) pool_free(c, d_slists);
+    if (p->nnz <= 0) pool_free(c, d_prod);
     if (p->nnz > 0) {
         // bin the rows of C: few nonzeros -> LDS hash kernels, the rest -> dense LDS tiles
-        PCHK(pool_get(c, (size_t)3 * m, &p->d_lists));
+        PCHK(pool_get(c, (size_t)4 * m, &p->d_lists));
         int *d_counts = (int *)((char *)c->d_flags + 192);
-        hipError_t e = hipMemsetAsync(d_counts, 0, 3 * sizeof(int), c->stream);
+        hipError_t e = hipMemsetAsync(d_counts, 0, 4 * sizeof(int), c->stream);
         LAUNCH(c, "smm_bin_rows", smm_bin_rows<int>, std::min<int64_t>((m + 1023) / 1024, 2048), 1024, 0, (int)m, c->hash_small,
-               c->hash_medium, (const int *)p->d_rowcnt, p->d_lists, d_counts);
-        if (e == hipSuccess) e = hipMemcpyAsync(p->n_bin, d_counts, 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+               c->hash_medium, (const int *)p->d_rowcnt, p->d_lists, d_counts, tiny_max, (const int64_t *)d_prod, a->ptr);
+        if (e == hipSuccess) e = hipMemcpyAsync(p->n_bin, d_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        pool_free(c, d_prod);
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "row binning: %s", hipGetErrorString(e)); }
     }
     if (p->b_sorted && p->n_bin[2] > 0) {
@@ -2015,6 +2040,17 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
                 else     LAUNCH(c, "smm_numeric_hash", (smm_numeric_hash<false, 4096, 4, 1>), grid, 256, 0, H);
             }
         }
+        LAUNCH_CHECK();
+    }
+    // tiny rows: four to a wave, first touch found among the lanes (always the reference's order of additions)
+    if (p->n_bin[3] > 0) {
+        const int nt = p->n_bin[3];
+        const int tgrid = (int)std::min<int64_t>(((int64_t)nt + 15) / 16, (int64_t)c->n_cu * 32);
+        const int *rows3 = p->d_lists + 3 * m;
+        if (sym) LAUNCH(c, "smm_numeric_tiny", smm_numeric_tiny<true>, tgrid, 256, 0, nt, rows3, p->row_offset, p->a->ptr, p->a->idx, p->a->val,
+                        p->b->ptr, p->b->idx, p->b->val, (const int64_t *)p->d_cptr, d_c_indices, d_c_data, c->d_err);
+        else     LAUNCH(c, "smm_numeric_tiny", smm_numeric_tiny<false>, tgrid, 256, 0, nt, rows3, p->row_offset, p->a->ptr, p->a->idx, p->a->val,
+                        p->b->ptr, p->b->idx, p->b->val, (const int64_t *)p->d_cptr, d_c_indices, d_c_data, c->d_err);
         LAUNCH_CHECK();
     }
     if (p->n_bin[2] == 0) return SMM_OK;

@@ -424,6 +424,27 @@ __global__ __launch_bounds__(256) void smm_row_work(int m, int ncols, int64_t ro
     }
 }
 
+// The same for operands whose rows are short on average (round 4: 30 M rows x 2 entries spent 5.7 ms in the kernel above,
+// one row per wave): one row per LANE.
+__global__ __launch_bounds__(256) void smm_row_work_short(int m, int ncols, int64_t row_offset, int sym,
+                                                          const int *__restrict__ a_ptr, const int *__restrict__ a_idx,
+                                                          const int *__restrict__ b_ptr, int64_t *__restrict__ products,
+                                                          int64_t *__restrict__ ub)
+{
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < m; row += gridDim.x * blockDim.x) {
+        int64_t s = 0;
+        const int a1 = a_ptr[row + 1];
+        for (int e = a_ptr[row]; e < a1; ++e) {
+            const int r = a_idx[e];
+            s += b_ptr[r + 1] - b_ptr[r];
+        }
+        products[row] = s;
+        int64_t cap = ncols;
+        if (sym) { const int64_t gi = row + row_offset; cap = gi < ncols ? ncols - gi : 0; }
+        if (ub) ub[row] = s < cap ? s : cap;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Exclusive scan, one 1024-thread workgroup walking the array (rows are at most a few 1e5).
 // out has n+1 entries; out[n] = total.
@@ -1942,23 +1963,32 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
 template <typename T>
 __global__ __launch_bounds__(1024) void smm_bin_rows(int m, int small_max, int med_max,
                                                      const T *__restrict__ rowcnt,
-                                                     int *__restrict__ lists, int *__restrict__ counts)
+                                                     int *__restrict__ lists, int *__restrict__ counts,
+                                                     int tiny_max = 0, const int64_t *__restrict__ tiny_ub = nullptr,
+                                                     const int *__restrict__ a_ptr = nullptr)
 {
-    __shared__ int wcnt[16][3], wbase[16][3];
+    // bin 3 (round 4): TINY rows -- at most tiny_max products (tiny_ub) from at most tiny_max entries of A -- which the
+    // smm_*_tiny kernels handle several to a wave; the predicate does not depend on rowcnt, so the symbolic and the
+    // numeric binning put the same rows there.
+    __shared__ int wcnt[16][4], wbase[16][4];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     for (int base = blockIdx.x * 1024; base < m; base += gridDim.x * 1024) {        // workgroup-uniform trip count
         const int row = base + threadIdx.x;
         const T n = row < m ? rowcnt[row] : 0;
-        const int b = n <= 0 ? -1 : (n <= small_max ? 0 : (n <= med_max ? 1 : 2));
+        int b = n <= 0 ? -1 : (n <= small_max ? 0 : (n <= med_max ? 1 : 2));
+        if (tiny_max > 0 && row < m) {
+            const int64_t u = tiny_ub[row];
+            if (u > 0 && u <= tiny_max && a_ptr[row + 1] - a_ptr[row] <= tiny_max) b = n > 0 ? 3 : -1;
+        }
         unsigned long long mine = 0ull;
 #pragma unroll
-        for (int bin = 0; bin < 3; ++bin) {
+        for (int bin = 0; bin < 4; ++bin) {
             const unsigned long long mask = __ballot(b == bin);
             if (b == bin) mine = mask;
             if (lane == 0) wcnt[wave][bin] = (int)__popcll(mask);
         }
         __syncthreads();
-        if (threadIdx.x < 3) {                              // one atomic per workgroup and bin, not per row
+        if (threadIdx.x < 4) {                              // one atomic per workgroup and bin, not per row
             int total = 0;
             for (int w = 0; w < 16; ++w) total += wcnt[w][threadIdx.x];
             int at = total ? atomicAdd(&counts[threadIdx.x], total) : 0;
@@ -1967,6 +1997,144 @@ __global__ __launch_bounds__(1024) void smm_bin_rows(int m, int small_max, int m
         __syncthreads();
         if (b >= 0) lists[(size_t)b * m + wbase[wave][b] + mbcnt(mine)] = row;
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// TINY rows (round 4): at most G products from at most G entries of A, G = 16 lanes per row, four rows per wave.
+// The hash kernels give every row a whole wave and a chain of ~5 dependent loads with ONE row in flight per wave: at
+// 4 entries per row 3 % of the lanes work (30 M rows x 2 entries: 35 + 33 ms).  Here lane p of a row's group IS
+// product p (entries of A in order, inside each the row of B in order -- the reference's loop order,
+// sparsework.cpp:59-76), so "first touch" needs no marker at all: a column is new iff no EARLIER lane of the group
+// carries it, found with G-1 DPP shifts inside the 16-lane row; its slot is the number of new lanes before it, and
+// the numeric kernel adds the later lanes of the same column to the first one in ascending order -- the reference's
+// order of additions, bit for bit.  B may be unsorted and may repeat columns (the earliest product wins, as in the
+// reference).  SYM: columns left of the diagonal are dropped (sparsework.cpp:160-167).
+constexpr int TINY_G = 16;
+struct TinyMap { int col; int k; int e; bool valid; int nprod; int excl; };
+template <bool SYM>
+__device__ __forceinline__ TinyMap tiny_map(const int row, const bool have, const int64_t row_offset, const int pl,
+                                            const int gbase, const int *__restrict__ a_ptr, const int *__restrict__ a_idx,
+                                            const int *__restrict__ b_ptr, const int *__restrict__ b_idx)
+{
+    // entry lanes: lane i of the group holds entry a0 + i (bs, len); product lanes: lane p holds product p
+    const int a0 = have ? a_ptr[row] : 0;
+    const int na = have ? a_ptr[row + 1] - a0 : 0;
+    const bool ev = pl < na && pl < TINY_G;
+    const int r = ev ? a_idx[a0 + pl] : 0;
+    const int bs = ev ? b_ptr[r] : 0;
+    int len = ev ? b_ptr[r + 1] - bs : 0;
+    len = len < 0 ? 0 : (len > TINY_G ? TINY_G + 1 : len);        // (a row beyond the class never gets here; clamped all the same)
+    // inclusive scan inside the 16-lane row
+    int incl = len;
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);
+    const int excl = incl - len;
+    int nprod = __shfl(incl, gbase + TINY_G - 1);
+    nprod = nprod > TINY_G ? 0 : nprod;                         // (never: the class holds rows with <= G products)
+    // product p = pl: its entry is the number of entries that end at or before p
+    int ej = 0;
+#pragma unroll
+    for (int sft = TINY_G / 2; sft > 0; sft >>= 1)
+        if (__shfl(incl, gbase + ej + sft - 1) <= pl) ej += sft;
+    const int e_bs = __shfl(bs, gbase + ej), e_ex = __shfl(excl, gbase + ej);
+    TinyMap t;
+    t.valid = pl < nprod;
+    t.k = t.valid ? e_bs + (pl - e_ex) : 0;
+    t.e = a0 + ej;
+    t.col = t.valid ? b_idx[t.k] : -1;
+    if (SYM) { const int64_t gi = row + row_offset; if (t.valid && (int64_t)t.col < gi) { t.valid = false; t.col = -1; } }
+    t.nprod = nprod;
+    t.excl = excl;
+    return t;
+}
+// dist = how many lanes back the FIRST lane with this lane's column sits (0: this lane is the first)
+template <int D>
+__device__ __forceinline__ void tiny_first(const int col, const int pl, int &dist)
+{
+    if constexpr (D < TINY_G) {
+        const int prev = __builtin_amdgcn_update_dpp(-2, col, 0x110 + D, 0xf, 0xf, false);      // row_shr:D (lanes shifted in keep -2)
+        if (pl >= D && prev == col) dist = D;
+        tiny_first<D + 1>(col, pl, dist);
+    }
+}
+template <bool SYM, typename IT>
+__global__ __launch_bounds__(256) void smm_symbolic_tiny(int nrows, const int *__restrict__ rowlist, int64_t row_offset,
+                                                         const int *__restrict__ a_ptr, const int *__restrict__ a_idx,
+                                                         const int *__restrict__ b_ptr, const int *__restrict__ b_idx,
+                                                         const int64_t *__restrict__ ub_off, IT *__restrict__ tmp_idx,
+                                                         unsigned *__restrict__ P, int *__restrict__ rowcnt)
+{
+    constexpr int RW = WAVE / TINY_G;                           // rows per wave
+    const int lane = lane_id(), pl = lane & (TINY_G - 1), g = lane / TINY_G, gbase = g * TINY_G;
+    const int wave = (int)(threadIdx.x >> 6), wpb = blockDim.x / WAVE;
+    for (int rb = (blockIdx.x * wpb + wave) * RW; rb < nrows; rb += gridDim.x * wpb * RW) {       // wave-uniform
+        const int ri = rb + g;
+        const bool have = ri < nrows;
+        const int row = have ? rowlist[ri] : 0;
+        const TinyMap t = tiny_map<SYM>(row, have, row_offset, pl, gbase, a_ptr, a_idx, b_ptr, b_idx);
+        int dist = 0;
+        tiny_first<1>(t.col, pl, dist);
+        const bool isnew = t.valid && dist == 0;
+        const unsigned gm = (unsigned)(__ballot(isnew) >> gbase) & ((1u << TINY_G) - 1u);
+        if (have) {
+            if (isnew) tmp_idx[ub_off[row] + __popc(gm & ((1u << pl) - 1u))] = (IT)t.col;
+            if (pl == 0) rowcnt[row] = __popc(gm);
+            // start slots: the list length when step e starts = new products before the entry's first product
+            const int na = a_ptr[row + 1] - a_ptr[row];
+            if (pl < na) P[a_ptr[row] + pl] = (unsigned)__popc(gm & ((1u << (t.excl < TINY_G ? t.excl : TINY_G)) - 1u));
+        }
+    }
+}
+template <int D>
+__device__ __forceinline__ void tiny_gather(const int col, const int pl, const bool valid, const double v, double &sum)
+{
+    if constexpr (D < TINY_G) {
+        const int nc = __builtin_amdgcn_update_dpp(-2, col, 0x100 + D, 0xf, 0xf, false);         // row_shl:D: lane pl + D
+        const unsigned long long vb = __builtin_bit_cast(unsigned long long, v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)vb, 0x100 + D, 0xf, 0xf, false);
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(vb >> 32), 0x100 + D, 0xf, 0xf, false);
+        const double nv = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+        if (valid && pl + D < TINY_G && nc == col) sum = sum + nv;
+        tiny_gather<D + 1>(col, pl, valid, v, sum);
+    }
+}
+template <bool SYM>
+__global__ __launch_bounds__(256) void smm_numeric_tiny(int nrows, const int *__restrict__ rowlist, int64_t row_offset,
+                                                        const int *__restrict__ a_ptr, const int *__restrict__ a_idx,
+                                                        const double *__restrict__ a_val, const int *__restrict__ b_ptr,
+                                                        const int *__restrict__ b_idx, const double *__restrict__ b_val,
+                                                        const int64_t *__restrict__ c_ptr, int *__restrict__ c_idx,
+                                                        double *__restrict__ c_val, unsigned *__restrict__ err)
+{
+    constexpr int RW = WAVE / TINY_G;
+    const int lane = lane_id(), pl = lane & (TINY_G - 1), g = lane / TINY_G, gbase = g * TINY_G;
+    const int wave = (int)(threadIdx.x >> 6), wpb = blockDim.x / WAVE;
+    for (int rb = (blockIdx.x * wpb + wave) * RW; rb < nrows; rb += gridDim.x * wpb * RW) {
+        const int ri = rb + g;
+        const bool have = ri < nrows;
+        const int row = have ? rowlist[ri] : 0;
+        const TinyMap t = tiny_map<SYM>(row, have, row_offset, pl, gbase, a_ptr, a_idx, b_ptr, b_idx);
+        const double v = t.valid ? a_val[t.e] * b_val[t.k] : 0.0;
+        int dist = 0;
+        tiny_first<1>(t.col, pl, dist);
+        const bool isnew = t.valid && dist == 0;
+        double sum = v;                                         // `values[index] = p` (sparsework.cpp:108), then += in product order
+        tiny_gather<1>(t.col, pl, isnew, v, sum);
+        const unsigned gm = (unsigned)(__ballot(isnew) >> gbase) & ((1u << TINY_G) - 1u);
+        if (have) {
+            const int64_t rs = c_ptr[row];
+            // (always on: the symbolic phase counted this row with the same map -- a different count would put stores
+            // into the neighbouring rows)
+            if ((int64_t)__popc(gm) != c_ptr[row + 1] - rs) { if (pl == 0) plan_err(err, PLAN_ERR_COUNT, row); }
+            else if (isnew) {
+                const int64_t at = rs + __popc(gm & ((1u << pl) - 1u));
+                c_idx[at] = t.col;
+                c_val[at] = sum;
+            }
+        }
     }
 }
 
