@@ -126,6 +126,9 @@ int  smm_ctx_tune_narrow(smm_ctx *ctx, int enable);
  * through a table of (source, length, destination) sub-runs -- which keeps the marker bitmaps small (many waves
  * per CU) and the lists 16-bit at any width.  Results do not depend on it, bit for bit. */
 int  smm_ctx_tune_symbolic(smm_ctx *ctx, int max_slab_cols);
+/* Symbolic walk for operands B with dense runs of columns (bands, blocks): 0 never, 1 (default) chosen per operand from the
+   share of neighbouring entries that fall into one 32-column word of the marker bitmap, 2 always.  Results never depend on it. */
+int  smm_ctx_tune_dense_runs(smm_ctx *ctx, int mode);
 /* Triple product, stage 2: ring != 0 selects the ring kernel of round 4 (the tile of T as a ring of column pieces, the
  * waves of a workgroup synchronised by progress words in LDS instead of barriers: csrc/smm_ring.hpp), 0 (default) the
  * chunk kernel.  Results are identical (bit for bit under SMM_EXACT); the ring is the slower of the two on MI355X

@@ -46,6 +46,7 @@ V2_PROTOTYPES = {
     "smm_ctx_tune_narrow": (ctypes.c_int, [_vp, ctypes.c_int]),
     "smm_ctx_exact_selftest": (ctypes.c_int, [_vp, ctypes.c_int]),
     "smm_ctx_tune_symbolic": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "smm_ctx_tune_dense_runs": (ctypes.c_int, [_vp, ctypes.c_int]),
     "smm_ctx_tune_stage2": (ctypes.c_int, [_vp, ctypes.c_int]),
     "smm_ctx_set_check": (ctypes.c_int, [_vp, ctypes.c_int]),
     "smm_ctx_release_pool": (ctypes.c_int, [_vp]),

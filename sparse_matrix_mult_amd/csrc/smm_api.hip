@@ -70,6 +70,8 @@ struct smm_ctx {
     int piece_walk = 1;      // default mode: one piece of B per wave iteration where every piece has <= 256 entries (env SMM_PIECE_WALK=0: chunk walk)
     int sym_max_ws = 0;      // widest column slab of that walk (0 = CCS_MAX_WS); B with more columns is walked slab by slab
                              // (smm_ctx_tune_symbolic; tests set it small to reach the slab path with small matrices)
+    int sym_dense = 1;       // symbolic walk over operands with dense runs of columns: 0 never, 1 chosen from B (>= 80 % of the neighbouring
+                             // entries share a bitmap word), 2 always (tests) -- env SMM_SYM_DENSE, smm_ctx_tune_dense_runs
     int numeric_persist = 1; // smm_numeric: persistent workgroups fed by a unit counter (env SMM_NUMERIC_PERSIST: 0 never, 1 CSR output without triangle, 2 always)
     int s2_ring = 0;         // triple stage 2: 1 = the ring kernel of round 4 (smm_ring.hpp: correct, measured 60-63 ms against 51 at
                              // BASELINE configs[3] -- kept as an alternative, env SMM_S2_RING=1 / smm_ctx_tune_stage2); 0 = the chunk kernel
@@ -218,6 +220,7 @@ extern "C" int smm_ctx_create(int device, void *hip_stream, smm_ctx **out)
     if (const char *e = getenv("SMM_S2_RING")) c->s2_ring = atoi(e) != 0;
     if (const char *e = getenv("SMM_NUMERIC_PERSIST")) c->numeric_persist = atoi(e);
     if (const char *e = getenv("SMM_TINY")) c->tiny_max = atoi(e) != 0 ? TINY_G : 0;
+    if (const char *e = getenv("SMM_SYM_DENSE")) c->sym_dense = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("SMM_SYM_WIDE")) c->sym_wide = atoi(e) != 0;
     if (const char *e = getenv("SMM_SYM_CCS")) c->sym_ccs = atoi(e) != 0;
     if (const char *e = getenv("SMM_PIECE_WALK")) c->piece_walk = atoi(e);
@@ -435,6 +438,14 @@ extern "C" int smm_ctx_tune_symbolic(smm_ctx *c, int max_slab_cols)
     CTX_LOCK(c);
     if (max_slab_cols < 0 || max_slab_cols > CCS_MAX_WS) return fail(SMM_ERR_INVALID, "slab width must be in [0,%d]", CCS_MAX_WS);
     c->sym_max_ws = max_slab_cols;
+    return SMM_OK;
+}
+extern "C" int smm_ctx_tune_dense_runs(smm_ctx *c, int mode)
+{
+    if (!c) return fail(SMM_ERR_INVALID, "ctx is NULL");
+    CTX_LOCK(c);
+    if (mode < 0 || mode > 2) return fail(SMM_ERR_INVALID, "mode must be 0 (never), 1 (chosen from the operand) or 2 (always)");
+    c->sym_dense = mode;
     return SMM_OK;
 }
 extern "C" int smm_ctx_tune_stage2(smm_ctx *c, int ring)
@@ -713,7 +724,7 @@ struct smm_csr {
     std::vector<SlabCache> slabs;
     std::vector<PackCache> packs;
     // chunk-padded 16-bit column stream per column slab (smm_ccs_*): the symbolic phase's gather stream
-    struct CcsCache { int ws, n_slabs, bm_words, guard_chunk; int *cptr; unsigned short *stream; };
+    struct CcsCache { int ws, n_slabs, bm_words, guard_chunk; int *cptr; unsigned short *stream; double same_word; };   // same_word: share of neighbouring entries in one bitmap word
     std::vector<CcsCache> ccs;
     unsigned short *idx16 = nullptr;             // 16-bit copy of idx (cols < 65535): the symbolic phase's gather stream
     int *idx_pad = nullptr;                      // borrowed operands with >= 65535 columns: a copy of idx with two ints of slack (wide symbolic walk)
@@ -1312,7 +1323,10 @@ static int ensure_ccs(smm_ctx *c, smm_csr *b, int ws, int n_slabs, smm_csr::CcsC
         if (e != hipSuccess) rc = fail(SMM_ERR_HIP, "chunked stream build: %s", hipGetErrorString(e));
     }
     if (rc == SMM_OK && total + 1 >= (INT32_MAX / CCS_CHUNK)) rc = fail(SMM_ERR_INVALID, "operand too large for the chunked column stream");
-    smm_csr::CcsCache e{ws, n_slabs, (ws + 31) / 32, (int)total, nullptr, nullptr};
+    smm_csr::CcsCache e{ws, n_slabs, (ws + 31) / 32, (int)total, nullptr, nullptr, 0.0};
+    unsigned long long *d_stat = nullptr;
+    if (rc == SMM_OK) rc = pool_get(c, 2, &d_stat);
+    if (rc == SMM_OK && hipMemsetAsync(d_stat, 0, 2 * sizeof(unsigned long long), c->stream) != hipSuccess) rc = fail(SMM_ERR_HIP, "memset");
     const int64_t ptr_entries = (int64_t)n_slabs * (b->rows + 1);
     if (rc == SMM_OK &&
         (dev_malloc(c, (void **)&e.cptr, (size_t)ptr_entries * sizeof(int)) != hipSuccess ||
@@ -1323,12 +1337,15 @@ static int ensure_ccs(smm_ctx *c, smm_csr *b, int ws, int n_slabs, smm_csr::CcsC
     if (rc == SMM_OK) {
         LAUNCH(c, "smm_ccs_ptr", smm_ccs_ptr, (ptr_entries + 255) / 256, 256, 0, (int)b->rows, n_slabs, (const int64_t *)off64, e.cptr);
         LAUNCH(c, "smm_ccs_fill", smm_ccs_fill, std::min<int64_t>(std::max<int64_t>((cells + 3) / 4, 1), 65536), 256, 0, (int)b->rows, n_slabs, ws,
-               e.bm_words, b->idx, seg, (const int *)e.cptr, e.stream);
+               e.bm_words, b->idx, seg, (const int *)e.cptr, e.stream, d_stat);
         hipError_t he = hipGetLastError();
+        unsigned long long stat[2] = {0, 0};
+        if (he == hipSuccess) he = hipMemcpyAsync(stat, d_stat, sizeof(stat), hipMemcpyDeviceToHost, c->stream);
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);        // chunks / off64 go back to the pool
+        e.same_word = stat[1] ? (double)stat[0] / (double)stat[1] : 0.0;
         if (he != hipSuccess) { (void)hipFree(e.cptr); (void)hipFree(e.stream); rc = fail(SMM_ERR_HIP, "chunked stream build: %s", hipGetErrorString(he)); }
     }
-    pool_free(c, chunks); pool_free(c, off64);
+    pool_free(c, chunks); pool_free(c, off64); pool_free(c, d_stat);
     if (rc != SMM_OK) return rc;
     b->ccs.push_back(e);
     b->derived_bytes += ptr_entries * (int64_t)sizeof(int) + (total + 1) * CCS_CHUNK * (int64_t)sizeof(unsigned short);
@@ -1795,7 +1812,9 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
                 const int64_t units = (int64_t)ns * m;
                 if (units >= INT32_MAX) { smm_plan_destroy(p); return fail(SMM_ERR_INVALID, "too many (slab, row) units"); }
                 const int sgrid = (int)std::min<int64_t>((units + cw - 1) / cw, (int64_t)c->n_cu * 8 * (4 / cw));
-                auto kern = sym ? smm_symbolic_ccs<true, SMM_CCS_UNROLL> : smm_symbolic_ccs<false, SMM_CCS_UNROLL>;
+                const bool dr = c->sym_dense == 2 || (c->sym_dense == 1 && cc.same_word >= 0.8);
+                auto kern = dr ? (sym ? smm_symbolic_ccs<true, SMM_CCS_UNROLL, true> : smm_symbolic_ccs<false, SMM_CCS_UNROLL, true>)
+                               : (sym ? smm_symbolic_ccs<true, SMM_CCS_UNROLL> : smm_symbolic_ccs<false, SMM_CCS_UNROLL>);
                 if (lds > 64 * 1024) {
                     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                     if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e)); }
@@ -1919,7 +1938,9 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         }
         const size_t lds = wave_bytes * cw;
         const int sgrid = (int)std::min<int64_t>((nbm + cw - 1) / cw, (int64_t)c->n_cu * 8 * (4 / cw));
-        auto kern = sym ? smm_symbolic_ccs<true, SMM_CCS_UNROLL> : smm_symbolic_ccs<false, SMM_CCS_UNROLL>;
+        const bool dr = c->sym_dense == 2 || (c->sym_dense == 1 && cc.same_word >= 0.8);
+        auto kern = dr ? (sym ? smm_symbolic_ccs<true, SMM_CCS_UNROLL, true> : smm_symbolic_ccs<false, SMM_CCS_UNROLL, true>)
+                       : (sym ? smm_symbolic_ccs<true, SMM_CCS_UNROLL> : smm_symbolic_ccs<false, SMM_CCS_UNROLL>);
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e)); }

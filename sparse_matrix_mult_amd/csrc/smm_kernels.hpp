@@ -847,13 +847,16 @@ __global__ __launch_bounds__(256) void smm_ccs_ptr(int rows, int n_slabs, const 
     cptr[gid] = (int)off64[(int64_t)s * rows + j];            // j == rows: the first chunk of the next slab = this slab's end
 }
 // one wave per (slab, row) piece
+// stat[0] += neighbouring entries of a piece that share a 32-column word of the marker bitmap, stat[1] += neighbouring
+// entries: the share tells the symbolic walk whether B has dense runs of columns (see smm_symbolic_ccs<.., DR>)
 __global__ __launch_bounds__(256) void smm_ccs_fill(int rows, int n_slabs, int ws, int bm_words, const int *__restrict__ idx,
                                                     const int *__restrict__ seg, const int *__restrict__ cptr,
-                                                    unsigned short *__restrict__ stream)
+                                                    unsigned short *__restrict__ stream, unsigned long long *__restrict__ stat)
 {
     const int lane = lane_id();
     const int wpb = blockDim.x / WAVE;
     const int64_t npieces = (int64_t)rows * n_slabs;
+    unsigned n_same = 0, n_pairs = 0;
     if (blockIdx.x == 0 && threadIdx.x < CCS_CHUNK)              // the all-guard chunk behind the last piece
         stream[(int64_t)cptr[(size_t)n_slabs * (rows + 1) - 1] * CCS_CHUNK + threadIdx.x] = (unsigned short)ccs_guard_col(bm_words, threadIdx.x);
     for (int64_t it = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); it < npieces; it += (int64_t)gridDim.x * wpb) {
@@ -863,8 +866,15 @@ __global__ __launch_bounds__(256) void smm_ccs_fill(int rows, int n_slabs, int w
         const int *cp = cptr + (size_t)s * (rows + 1) + j;
         const int64_t base = (int64_t)cp[0] * CCS_CHUNK;
         const int total = (cp[1] - cp[0]) * CCS_CHUNK;
-        for (int p = lane; p < total; p += WAVE)
-            stream[base + p] = (unsigned short)(p < len ? idx[k0 + p] - s * ws : ccs_guard_col(bm_words, p & (CCS_CHUNK - 1)));
+        for (int p = lane; p < total; p += WAVE) {
+            const int col = p < len ? idx[k0 + p] - s * ws : ccs_guard_col(bm_words, p & (CCS_CHUNK - 1));
+            stream[base + p] = (unsigned short)col;
+            if (p + 1 < len) { ++n_pairs; n_same += ((idx[k0 + p + 1] - s * ws) >> 5) == (col >> 5) ? 1u : 0u; }
+        }
+    }
+    if (stat) {
+        for (int o = 32; o > 0; o >>= 1) { n_same += __shfl_xor(n_same, o); n_pairs += __shfl_xor(n_pairs, o); }
+        if (lane == 0 && n_pairs) { atomicAdd(&stat[0], (unsigned long long)n_same); atomicAdd(&stat[1], (unsigned long long)n_pairs); }
     }
 }
 // products of every (slab, row of A) unit: the capacity of its ordered list is min(products, slab columns that can appear)
@@ -900,7 +910,16 @@ __global__ __launch_bounds__(256) void smm_ccs_row_work(int m, int n_slabs, int 
 //   unit u (handed out by a global counter, slab-major): slab s = u / nrows, row = rowlist[u % nrows]
 //   list_off[s * m + row]   where the unit's list starts in tmp (uint16, slab-local columns)
 //   P[s * nnzA + e]         list length of the unit when step e starts;  cnt[s * m + row] final length
-template <bool SYM, int UNROLL>
+//
+// DR (round 4, operands with DENSE RUNS of columns: bands, blocks): 128 consecutive columns are 4 bitmap words, i.e. 16 lanes
+// of one returning atomic on ONE address, which the LDS serialises at 3.3 cycles per lane (53 instead of 9 cycles per wave
+// instruction, scripts/ubench/lds_or_sameword.hip) -- 28 of the 65 ms of a band of half-width 200.  Same-address READS are
+// broadcast, and the columns of a chunk are distinct, so here the test reads the words plainly and the set is one
+// non-returning OR per group of up to four lanes: a lane's two columns merged when they share a word, then two DPP steps
+// of a segmented OR over neighbouring lanes with the same word.  The ~15 extra vector instructions per chunk are what the
+// uniform-random walk cannot afford (profiles/r4_symbolic_lean.txt), hence a second instantiation, chosen from the
+// share of neighbouring entries of B that share a word (smm_ccs_fill).
+template <bool SYM, int UNROLL, bool DR = false>
 __global__ __launch_bounds__(256) void smm_symbolic_ccs(int m, int n_slabs, const int *__restrict__ rowlist, const int *__restrict__ nrows_p,
                                                         int64_t row_offset, int ws, int bm_words, int rowsB, int64_t nnzA, int guard_chunk,
                                                         const int *__restrict__ a_ptr, const int *__restrict__ a_idx,
@@ -977,8 +996,30 @@ __global__ __launch_bounds__(256) void smm_symbolic_ccs(int m, int n_slabs, cons
                             if (SYM) { lo = lo >= thresh ? lo : guard; hi = hi >= thresh ? hi : guard; }
                             c[u] = lo; ch[u] = hi;
                             bitl[u] = 1u << (lo & 31); bith[u] = 1u << (hi & 31);
-                            oldl[u] = atomicOr(bm + (lo >> 5), bitl[u]);
-                            oldh[u] = atomicOr(bm + (hi >> 5), bith[u]);
+                            if constexpr (!DR) {
+                                oldl[u] = atomicOr(bm + (lo >> 5), bitl[u]);
+                                oldh[u] = atomicOr(bm + (hi >> 5), bith[u]);
+                            } else {
+                                const int wl = lo >> 5, wh = hi >> 5;
+                                oldl[u] = bm[wl];                   // (one wave, one bitmap, LDS in issue order: these see every OR of the chunks before)
+                                oldh[u] = bm[wh];
+                                const bool same = wl == wh;
+                                unsigned mm = bitl[u] | (same ? bith[u] : 0u);
+                                {   // segmented OR over lanes i-1, then i-2 .. i-3, of the 16-lane row (words ascend with the lanes)
+                                    const int pw1 = __builtin_amdgcn_update_dpp(-1, wl, 0x111, 0xf, 0xf, false);
+                                    const unsigned pm1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mm, 0x111, 0xf, 0xf, false);
+                                    if (pw1 == wl) mm |= pm1;
+                                    const int pw2 = __builtin_amdgcn_update_dpp(-1, wl, 0x112, 0xf, 0xf, false);
+                                    const unsigned pm2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mm, 0x112, 0xf, 0xf, false);
+                                    if (pw2 == wl) mm |= pm2;
+                                }
+                                // the last lane of every run of (at most four) lanes with one word issues the OR.  A lane whose
+                                // successor has the same word has been merged into it by the steps above iff the run is not cut
+                                // by the step pattern: lanes 4k+3 and row ends always issue.
+                                const int nw = __builtin_amdgcn_update_dpp(-1, wl, 0x101, 0xf, 0xf, false);     // row_shl:1 = lane + 1
+                                if (nw != wl || (lane & 3) == 3) (void)__hip_atomic_fetch_or(bm + wl, mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (!same) (void)__hip_atomic_fetch_or(bm + wh, bith[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

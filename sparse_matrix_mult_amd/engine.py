@@ -85,6 +85,10 @@ class Context:
         """Widest column slab of the symbolic walk (0 = default 63456); a wider B is walked slab by slab."""
         check(self.lib, self.lib.smm_ctx_tune_symbolic(self.handle, int(max_slab_cols)))
 
+    def tune_dense_runs(self, mode=1):
+        """Symbolic walk for operands with dense runs of columns: 0 never, 1 chosen per operand (default), 2 always."""
+        check(self.lib, self.lib.smm_ctx_tune_dense_runs(self.handle, int(mode)))
+
     def tune_stage2(self, ring=False):
         """Triple product, stage 2: the ring kernel of round 4 (True) or the chunk kernel (False, default)."""
         check(self.lib, self.lib.smm_ctx_tune_stage2(self.handle, 1 if ring else 0))

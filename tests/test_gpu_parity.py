@@ -15,24 +15,28 @@ from helpers import wide_csr, arrays, assert_csr_equal, rand_csr, rel_err, shuff
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["hash+tiles", "tiles-only", "small-hash", "slab-all", "slab-narrow", "idx32"], autouse=True)
+@pytest.fixture(params=["hash+tiles", "tiles-only", "small-hash", "slab-all", "slab-narrow", "idx32", "dense-runs"], autouse=True)
 def numeric_paths(request, ctx):
     """Every case runs with the default dispatch (rows with few nonzeros -> LDS hash kernels, the
     rest -> dense LDS tiles), with the hash kernels off, with only the one-wave hash kernel
     on and a low threshold (mixes all three kernels inside one product), and with the row-block x
     column-slab kernels forced (L2-sized slabs for every row; 50-column slabs next to the hash kernels); "idx32"
     switches the 16-bit column stream / lists of the symbolic phase off (every other configuration has them on
-    wherever B has < 65535 columns)."""
+    wherever B has < 65535 columns); "dense-runs" forces the symbolic walk's instantiation for operands with dense runs of
+    columns (plain reads + merged ORs instead of returning atomics, round 4) on every operand, hash kernels off."""
     hash_cfg, slab_cfg = {"hash+tiles": ((256, 2048), (0, 0, 4)), "tiles-only": ((0, 0), (0, 0, 4)),
                           "small-hash": ((24, 150), (0, 0, 4)), "slab-all": ((0, 0), (2, 0, 4)),
-                          "slab-narrow": ((24, 150), (2, 50, 2)), "idx32": ((24, 150), (0, 0, 4))}[request.param]
+                          "slab-narrow": ((24, 150), (2, 50, 2)), "idx32": ((24, 150), (0, 0, 4)),
+                          "dense-runs": ((0, 0), (0, 0, 4))}[request.param]
     ctx.tune_hash(*hash_cfg)
     ctx.tune_slab(*slab_cfg)
     ctx.tune_narrow(request.param != "idx32")
+    ctx.tune_dense_runs(2 if request.param == "dense-runs" else 1)
     yield
     ctx.tune_hash(256, 2048)
     ctx.tune_slab(0, 0, 4)
     ctx.tune_narrow(True)
+    ctx.tune_dense_runs(1)
 
 RTOL = 1e-10   # north star: "float64 values within 1e-10 relative"
 

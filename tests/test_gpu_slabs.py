@@ -111,6 +111,7 @@ def test_slab_path_fuzz(ctx, oracle, it):
     if A is None or B is None or np.diff(B.indptr)[A.indices].sum() > 2e7:
         pytest.skip("case larger than the budget")
     ctx.tune_shared(cols, waves); ctx.tune(cols, min(waves, 8)); ctx.tune_symbolic(ws)
+    ctx.tune_dense_runs(2 if it % 3 == 1 else 1)          # every third case: the dense-run instantiation of the slab walk
     a, b = ctx.csr_from_scipy(A), ctx.csr_from_scipy(B)
     try:
         for sym in ((False, True) if m == n else (False,)):
@@ -122,4 +123,4 @@ def test_slab_path_fuzz(ctx, oracle, it):
             assert np.all(np.abs(gv - want[2]) <= 1e-12 * mag)
     finally:
         a.close(); b.close()
-        ctx.tune_shared(20000, 16); ctx.tune(18000, 8); ctx.tune_symbolic(0)
+        ctx.tune_shared(20000, 16); ctx.tune(18000, 8); ctx.tune_symbolic(0); ctx.tune_dense_runs(1)

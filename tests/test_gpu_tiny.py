@@ -145,3 +145,27 @@ def test_switch_off(ctx, oracle, monkeypatch):
         assert launches["smm_symbolic_tiny"] == 0 and launches["smm_numeric_tiny"] == 0 and launches["smm_numeric_hash"] >= 1
     finally:
         c2.close()
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+@pytest.mark.parametrize("family", ["band", "blocks"])
+def test_dense_runs_are_detected_and_walked_by_the_merged_or_kernel(ctx, oracle, family, symmetric):
+    """Operands with dense runs of columns (round 4): chosen automatically (>= 80 % of the neighbouring entries of B share a
+    bitmap word), same first-touch order as the oracle; a uniform random operand keeps the returning-atomic walk."""
+    rng = np.random.default_rng(23)
+    n = 3000
+    if family == "band":
+        offs = np.arange(-60, 61)
+        B = sp.diags([rng.uniform(-1, 1, n - abs(o)) for o in offs], offs, shape=(n, n), format="csr")
+    else:
+        B = sp.block_diag([sp.random(150, 150, density=0.6, format="csr", random_state=rng) for _ in range(n // 150)], format="csr")
+    B.sort_indices()
+    A = sp.random(n, n, density=0.01, format="csr", random_state=rng)
+    want = oracle.sparse(arrays(A), arrays(B), n, symmetric=symmetric)
+    ctx.tune_hash(0, 0)                                     # every row through the bitmap walk
+    try:
+        for exact in (False, True):
+            got, _ = _gpu(ctx, A, B, symmetric=symmetric, exact=exact)
+            assert_csr_equal(got, want, values="bits" if exact else "tol")
+    finally:
+        ctx.tune_hash(256, 2048)
