@@ -949,10 +949,17 @@ __global__ __launch_bounds__(256) void smm_symbolic_ccs(int m, int n_slabs, cons
         const int *__restrict__ cp = cptr + (size_t)s * (rowsB + 1);
         int thresh = 0;                                         // SYM: slab-local columns below the diagonal are dropped
         if (SYM) { const int64_t d = row + row_offset - (int64_t)s * ws; thresh = d < 0 ? 0 : (d > ws ? ws : (int)d); }
-        unsigned short *__restrict__ out = tmp + list_off[(size_t)s * m + row];
+        const int64_t lo_off = list_off[(size_t)s * m + row];
+        unsigned short *__restrict__ out = tmp + lo_off;
         unsigned *__restrict__ Ps = P + (size_t)s * nnzA;
         int n = 0;
-        if (a1 > a0) {
+        // (round 4) a unit whose list has no capacity has no product in this slab -- most (slab, row) units of a banded or
+        // block operand: its start slots are all 0, and nothing else is read (the walk would still fetch two chunk pointers
+        // per entry of A to find every piece empty)
+        const bool no_products = __builtin_amdgcn_readfirstlane((int)(list_off[(size_t)s * m + row + 1] != lo_off)) == 0;   // wave-uniform
+        if (no_products) {
+            for (int e = a0 + lane; e < a1; e += WAVE) Ps[e] = 0u;
+        } else if (a1 > a0) {
             auto load_r = [&](int jb) { int e = jb + lane; e = e < a1 ? e : a1 - 1; return a_idx[e]; };
             int r_c = load_r(a0), r_n = load_r(a0 + WAVE);
             int cs = cp[r_c], ce = cp[r_c + 1];
