@@ -1709,10 +1709,17 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     PCHK(pool_get(c, (size_t)m, &d_ub));
     PCHK(pool_get(c, (size_t)m + 1, &p->d_ub_off));
     const int wgrid = (int)std::min<int64_t>((m + 3) / 4, 16384);
-    if (a->nnz <= 8 * m)         // short rows on average: a row per lane instead of a row per wave
+    if (a->nnz <= 8 * m) {       // short rows on average: a row per lane instead of a row per wave; rows beyond 32 entries on a list
+        int *d_long = nullptr;
+        PCHK(pool_get(c, (size_t)(a->nnz / ROW_WORK_SHORT_MAX + 2), &d_long));      // [0]: count, [1 ...]: rows
+        hipError_t e = hipMemsetAsync(d_long, 0, sizeof(int), c->stream);
+        if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "memset: %s", hipGetErrorString(e)); }
         LAUNCH(c, "smm_row_work", smm_row_work_short, (int)std::min<int64_t>((m + 255) / 256, 65536), 256, 0, (int)m, (int)p->ncols,
+               p->row_offset, sym ? 1 : 0, a->ptr, a->idx, b->ptr, d_prod, d_ub, d_long + 1, d_long);
+        LAUNCH(c, "smm_row_work", smm_row_work_listed, c->n_cu * 8, 256, 0, (const int *)d_long, (const int *)(d_long + 1), (int)p->ncols,
                p->row_offset, sym ? 1 : 0, a->ptr, a->idx, b->ptr, d_prod, d_ub);
-    else
+        pool_free(c, d_long);           // stream-ordered: only work queued behind these launches can get it
+    } else
         LAUNCH(c, "smm_row_work", smm_row_work, wgrid, 256, 0, (int)m, (int)p->ncols, p->row_offset, sym ? 1 : 0, a->ptr,
                a->idx, b->ptr, d_prod, d_ub);
     PCHK(scan_launch<int64_t>(c, m, d_ub, p->d_ub_off));
@@ -1893,7 +1900,7 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         const int *rows3 = d_slists + (size_t)3 * m;
 #define TINY_CASE(S, IT)                                                                                                        \
         LAUNCH(c, "smm_symbolic_tiny", (smm_symbolic_tiny<S, IT>), tgrid, 256, 0, sbin[3], rows3, p->row_offset, a->ptr, a->idx,  \
-               b->ptr, b->idx, (const int64_t *)p->d_ub_off, (IT *)p->d_tmp, p->d_P, p->d_rowcnt);
+               b->ptr, b->idx, (const int64_t *)p->d_ub_off, (IT *)p->d_tmp, p->d_P, p->d_rowcnt, c->d_err);
         if (p->list16) { if (sym) { TINY_CASE(true, unsigned short) } else { TINY_CASE(false, unsigned short) } }
         else           { if (sym) { TINY_CASE(true, int) } else { TINY_CASE(false, int) } }
 #undef TINY_CASE

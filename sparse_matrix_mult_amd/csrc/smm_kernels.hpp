@@ -425,16 +425,21 @@ __global__ __launch_bounds__(256) void smm_row_work(int m, int ncols, int64_t ro
 }
 
 // The same for operands whose rows are short on average (round 4: 30 M rows x 2 entries spent 5.7 ms in the kernel above,
-// one row per wave): one row per LANE.
+// one row per wave): one row per LANE.  A row with more than ROW_WORK_SHORT_MAX entries (a hub of a power-law operand
+// would keep its one lane busy for 1e6 dependent iterations) is put on a list instead and gets a wave of its own in
+// smm_row_work_listed.
+constexpr int ROW_WORK_SHORT_MAX = 32;
 __global__ __launch_bounds__(256) void smm_row_work_short(int m, int ncols, int64_t row_offset, int sym,
                                                           const int *__restrict__ a_ptr, const int *__restrict__ a_idx,
                                                           const int *__restrict__ b_ptr, int64_t *__restrict__ products,
-                                                          int64_t *__restrict__ ub)
+                                                          int64_t *__restrict__ ub, int *__restrict__ long_rows,
+                                                          int *__restrict__ n_long)
 {
     for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < m; row += gridDim.x * blockDim.x) {
         int64_t s = 0;
-        const int a1 = a_ptr[row + 1];
-        for (int e = a_ptr[row]; e < a1; ++e) {
+        const int a0 = a_ptr[row], a1 = a_ptr[row + 1];
+        if (a1 - a0 > ROW_WORK_SHORT_MAX) { long_rows[atomicAdd(n_long, 1)] = row; continue; }
+        for (int e = a0; e < a1; ++e) {
             const int r = a_idx[e];
             s += b_ptr[r + 1] - b_ptr[r];
         }
@@ -442,6 +447,30 @@ __global__ __launch_bounds__(256) void smm_row_work_short(int m, int ncols, int6
         int64_t cap = ncols;
         if (sym) { const int64_t gi = row + row_offset; cap = gi < ncols ? ncols - gi : 0; }
         if (ub) ub[row] = s < cap ? s : cap;
+    }
+}
+__global__ __launch_bounds__(256) void smm_row_work_listed(const int *__restrict__ n_rows, const int *__restrict__ rows, int ncols,
+                                                           int64_t row_offset, int sym, const int *__restrict__ a_ptr,
+                                                           const int *__restrict__ a_idx, const int *__restrict__ b_ptr,
+                                                           int64_t *__restrict__ products, int64_t *__restrict__ ub)
+{
+    const int lane = lane_id();
+    const int wpb = blockDim.x / WAVE;
+    const int n = *n_rows;
+    for (int ri = blockIdx.x * wpb + (threadIdx.x >> 6); ri < n; ri += gridDim.x * wpb) {
+        const int row = rows[ri];
+        int64_t s = 0;
+        for (int e = a_ptr[row] + lane; e < a_ptr[row + 1]; e += WAVE) {
+            const int r = a_idx[e];
+            s += b_ptr[r + 1] - b_ptr[r];
+        }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+        if (lane == 0) {
+            products[row] = s;
+            int64_t cap = ncols;
+            if (sym) { const int64_t gi = row + row_offset; cap = gi < ncols ? ncols - gi : 0; }
+            if (ub) ub[row] = s < cap ? s : cap;
+        }
     }
 }
 
@@ -2081,7 +2110,7 @@ __device__ __forceinline__ TinyMap tiny_map(const int row, const bool have, cons
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);
     const int excl = incl - len;
     int nprod = __shfl(incl, gbase + TINY_G - 1);
-    nprod = nprod > TINY_G ? 0 : nprod;                         // (never: the class holds rows with <= G products)
+    nprod = (nprod > TINY_G || na > TINY_G) ? -1 : nprod;       // (never: the class holds rows with <= G products from <= G entries; reported)
     // product p = pl: its entry is the number of entries that end at or before p
     int ej = 0;
 #pragma unroll
@@ -2113,7 +2142,7 @@ __global__ __launch_bounds__(256) void smm_symbolic_tiny(int nrows, const int *_
                                                          const int *__restrict__ a_ptr, const int *__restrict__ a_idx,
                                                          const int *__restrict__ b_ptr, const int *__restrict__ b_idx,
                                                          const int64_t *__restrict__ ub_off, IT *__restrict__ tmp_idx,
-                                                         unsigned *__restrict__ P, int *__restrict__ rowcnt)
+                                                         unsigned *__restrict__ P, int *__restrict__ rowcnt, unsigned *__restrict__ err)
 {
     constexpr int RW = WAVE / TINY_G;                           // rows per wave
     const int lane = lane_id(), pl = lane & (TINY_G - 1), g = lane / TINY_G, gbase = g * TINY_G;
@@ -2127,7 +2156,8 @@ __global__ __launch_bounds__(256) void smm_symbolic_tiny(int nrows, const int *_
         tiny_first<1>(t.col, pl, dist);
         const bool isnew = t.valid && dist == 0;
         const unsigned gm = (unsigned)(__ballot(isnew) >> gbase) & ((1u << TINY_G) - 1u);
-        if (have) {
+        if (have && t.nprod < 0) { if (pl == 0) { plan_err(err, PLAN_ERR_COUNT, row); rowcnt[row] = 0; } }
+        else if (have) {
             if (isnew) tmp_idx[ub_off[row] + __popc(gm & ((1u << pl) - 1u))] = (IT)t.col;
             if (pl == 0) rowcnt[row] = __popc(gm);
             // start slots: the list length when step e starts = new products before the entry's first product

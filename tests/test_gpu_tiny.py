@@ -169,3 +169,23 @@ def test_dense_runs_are_detected_and_walked_by_the_merged_or_kernel(ctx, oracle,
             assert_csr_equal(got, want, values="bits" if exact else "tol")
     finally:
         ctx.tune_hash(256, 2048)
+
+
+def test_short_rows_with_a_few_hubs(ctx, oracle):
+    """nnz(A) <= 8 rows: the per-lane row-work kernel; rows beyond 32 entries take the listed per-wave kernel."""
+    rng = np.random.default_rng(29)
+    n = 50_000
+    lens = np.full(n, 2)
+    lens[[5, 777, 49_999]] = [5000, 33, 20000]
+    A = _rows(lens, n, rng)
+    B = _rows(rng.integers(0, 5, n), n, rng)
+    want = oracle.sparse(arrays(A), arrays(B), n)
+    got, launches = _gpu(ctx, A, B, exact=True)
+    assert_csr_equal(got, want, values="bits")
+    assert launches["smm_symbolic_tiny"] == 1
+    a, b = ctx.csr_from_scipy(A), ctx.csr_from_scipy(B)
+    try:
+        assert np.array_equal(ctx.row_products(a, b), np.diff(B.indptr)[A.indices].astype(np.int64).cumsum()[A.indptr[1:] - 1] -
+                              np.concatenate(([0], np.diff(B.indptr)[A.indices].astype(np.int64).cumsum()))[A.indptr[:-1]])
+    finally:
+        a.close(); b.close()
