@@ -234,7 +234,7 @@ extern "C" int smm_ctx_create(int device, void *hip_stream, smm_ctx **out)
         if (e != hipSuccess) { delete c; return fail(SMM_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
         c->own_stream = true;
     }
-    if (hipMalloc((void **)&c->d_flags, 256) != hipSuccess) { delete c; return fail(SMM_ERR_ALLOC, "hipMalloc flags"); }
+    if (hipMalloc((void **)&c->d_flags, 512) != hipSuccess) { delete c; return fail(SMM_ERR_ALLOC, "hipMalloc flags"); }    // (+256: bin counts, +288 / +320: row counters)
     {
         unsigned char init[256];
         memset(init, 0, sizeof(init));
@@ -1726,32 +1726,39 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     // The marker of the symbolic phase is a bitmap of B's columns (ncols/8 bytes per wave, in LDS when
     // it fits): at 50 000 columns 24 waves fit a CU, at 1e6 columns one.  Rows with few products --
     // known now -- therefore take an LDS hash set instead, wherever that is the smaller marker:
-    //   class 0: <= 256 products, 512 slots (2 KB per wave); class 1: <= 2048 products, 4096 slots (16 KB).
+    //   four classes: <= 256 / 512 / 1024 / 2048 products in 512 / 1024 / 2048 / 4096 slots (2 ... 16 KB per wave; round 4:
+    //   there used to be two, and a band of half-width 8 -- 289 products, 33 columns per row -- ran 8 waves per CU in the
+    //   4096-slot class: 11.6 ms; in the 1024-slot class 4.9 ms).
     const int bm_words = (int)((p->ncols + 31) / 32);
     const size_t bm_bytes = (size_t)(bm_words + 1) * sizeof(unsigned);      // + the guard word
     const bool ldsbm = bm_bytes <= 128 * 1024;
     const bool safe = (b->vflags & (CSR_HAS_EQUAL | CSR_UNSORTED)) != 0;
-    constexpr int HS0 = 512, HS1 = 4096;
-    const int hmax0 = (!safe && bm_bytes > HS0 * 4) ? HS0 / 2 : 0;
-    const int hmax1 = (!safe && bm_bytes > HS1 * 4) ? HS1 / 2 : hmax0;
+    constexpr int NHC = 4;
+    constexpr int HS[NHC] = {512, 1024, 2048, 4096};
+    int hmax[NHC];
+    for (int i = 0; i < NHC; ++i) hmax[i] = (!safe && bm_bytes > (size_t)HS[i] * 4) ? HS[i] / 2 : (i ? hmax[i - 1] : 0);
+    const int hmax1 = hmax[NHC - 1];
+    constexpr int SB_REST = NHC, SB_TINY = NHC + 1, SB_N = NHC + 2;      // bins of the symbolic phase: hash classes, bitmap, tiny
     // ... and TINY rows (<= 16 products from <= 16 entries of A, whatever B looks like) go four to a wave (smm_symbolic_tiny)
     const int tiny_max = c->tiny_max;
     const bool binned = hmax1 > 0 || tiny_max > 0;
-    int sbin[4] = {0, 0, (int)m, 0};
+    int sbin[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    sbin[SB_REST] = (int)m;
     int *d_slists = nullptr;
-    int *d_scounts = (int *)((char *)c->d_flags + 224);
+    int *d_scounts = (int *)((char *)c->d_flags + 256);
     if (binned) {
-        PCHK(pool_get(c, (size_t)4 * m, &d_slists));
-        hipError_t e = hipMemsetAsync(d_scounts, 0, 4 * sizeof(int), c->stream);
+        PCHK(pool_get(c, (size_t)SB_N * m, &d_slists));
+        hipError_t e = hipMemsetAsync(d_scounts, 0, 8 * sizeof(int), c->stream);
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "memset: %s", hipGetErrorString(e)); }
-        LAUNCH(c, "smm_bin_rows", smm_bin_rows<int64_t>, std::min<int64_t>((m + 1023) / 1024, 2048), 1024, 0, (int)m, hmax0, hmax1,
+        BinSpec spec{NHC, {hmax[0], hmax[1], hmax[2], hmax[3], 0, 0}, SB_TINY};
+        LAUNCH(c, "smm_bin_rows", smm_bin_rows<int64_t>, std::min<int64_t>((m + 1023) / 1024, 2048), 1024, 0, (int)m, spec,
                (const int64_t *)d_ub, d_slists, d_scounts, tiny_max, (const int64_t *)d_prod, a->ptr);
     }
     int64_t total_ub = 0;
     {
         hipError_t e = hipMemcpyAsync(&total_ub, p->d_ub_off + m, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess && binned)
-            e = hipMemcpyAsync(sbin, d_scounts, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+            e = hipMemcpyAsync(sbin, d_scounts, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "row work: %s", hipGetErrorString(e)); }
     }
@@ -1761,7 +1768,7 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     {
         const int ws_cap = c->sym_max_ws > 0 ? c->sym_max_ws : CCS_MAX_WS;
         const bool wide = p->ncols > ws_cap && p->g.wc <= ws_cap && p->g.wc <= 32767;
-        const bool dominant = c->sym_max_ws > 0 || hmax1 == 0 || 2 * (int64_t)sbin[2] >= m;
+        const bool dominant = c->sym_max_ws > 0 || hmax1 == 0 || 2 * (int64_t)sbin[SB_REST] >= m;
         if (c->sym_ccs && c->narrow_idx && wide && dominant && !safe && p->b_sorted && c->slab_mode != 2) {
             if (d_slists) pool_free(c, d_slists);
             pool_free(c, d_prod);
@@ -1842,9 +1849,10 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
             if (p->nnz > 0) {
                 // every non-empty row goes to the tile kernel (the hash kernels read one list per row)
                 PCHK(pool_get(c, (size_t)4 * m, &p->d_lists));
-                int *d_counts = (int *)((char *)c->d_flags + 192);
-                hipError_t e = hipMemsetAsync(d_counts, 0, 4 * sizeof(int), c->stream);
-                LAUNCH(c, "smm_bin_rows", smm_bin_rows<int>, std::min<int64_t>((m + 1023) / 1024, 2048), 1024, 0, (int)m, 0, 0,
+                int *d_counts = (int *)((char *)c->d_flags + 320);
+                hipError_t e = hipMemsetAsync(d_counts, 0, 8 * sizeof(int), c->stream);
+                BinSpec nspec{2, {0, 0, 0, 0, 0, 0}, 3};
+                LAUNCH(c, "smm_bin_rows", smm_bin_rows<int>, std::min<int64_t>((m + 1023) / 1024, 2048), 1024, 0, (int)m, nspec,
                        (const int *)p->d_rowcnt, p->d_lists, d_counts);
                 if (e == hipSuccess) e = hipMemcpyAsync(p->n_bin, d_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1889,17 +1897,17 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     }
 
     // the kernels hand rows out through these counters (one per launch)
-    int *d_rowctr = (int *)((char *)c->d_flags + 208);
+    int *d_rowctr = (int *)((char *)c->d_flags + 288);
     {
-        hipError_t e = hipMemsetAsync(d_rowctr, 0, 3 * sizeof(int), c->stream);
+        hipError_t e = hipMemsetAsync(d_rowctr, 0, 8 * sizeof(int), c->stream);
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "memset: %s", hipGetErrorString(e)); }
     }
     // tiny rows: four to a wave, no marker at all
-    if (sbin[3] > 0) {
-        const int tgrid = (int)std::min<int64_t>(((int64_t)sbin[3] + 15) / 16, (int64_t)c->n_cu * 32);
-        const int *rows3 = d_slists + (size_t)3 * m;
+    if (sbin[SB_TINY] > 0) {
+        const int tgrid = (int)std::min<int64_t>(((int64_t)sbin[SB_TINY] + 15) / 16, (int64_t)c->n_cu * 32);
+        const int *rows3 = d_slists + (size_t)SB_TINY * m;
 #define TINY_CASE(S, IT)                                                                                                        \
-        LAUNCH(c, "smm_symbolic_tiny", (smm_symbolic_tiny<S, IT>), tgrid, 256, 0, sbin[3], rows3, p->row_offset, a->ptr, a->idx,  \
+        LAUNCH(c, "smm_symbolic_tiny", (smm_symbolic_tiny<S, IT>), tgrid, 256, 0, sbin[SB_TINY], rows3, p->row_offset, a->ptr, a->idx,  \
                b->ptr, b->idx, (const int64_t *)p->d_ub_off, (IT *)p->d_tmp, p->d_P, p->d_rowcnt, c->d_err);
         if (p->list16) { if (sym) { TINY_CASE(true, unsigned short) } else { TINY_CASE(false, unsigned short) } }
         else           { if (sym) { TINY_CASE(true, int) } else { TINY_CASE(false, int) } }
@@ -1908,18 +1916,18 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "smm_symbolic_tiny: %s", hipGetErrorString(e)); }
     }
     // hash classes: one wave per row, four rows per workgroup
-    for (int cls = 0; cls < 2; ++cls) {
+    for (int cls = 0; cls < NHC; ++cls) {
         if (hmax1 == 0 || sbin[cls] == 0) continue;
-        const int hs = cls == 0 ? HS0 : HS1;
+        const int hs = HS[cls];
         const int hgrid = (int)std::min<int64_t>((sbin[cls] + 3) / 4, (int64_t)c->n_cu * 16);
         if (sym) PCHK((launch_symbolic_t<true, false, MARK_LDS_HASH>(c, p, hs, nullptr, hgrid, 4, d_slists + (size_t)cls * m, d_scounts + cls, d_rowctr + cls)));
         else     PCHK((launch_symbolic_t<false, false, MARK_LDS_HASH>(c, p, hs, nullptr, hgrid, 4, d_slists + (size_t)cls * m, d_scounts + cls, d_rowctr + cls)));
     }
     // bitmap kernels for the rest: one wave per row; waves per workgroup are chosen so that as many
     // waves as possible fit a CU's 160 KB
-    const int64_t nbm = binned ? sbin[2] : m;
-    const int *bm_rows = binned ? d_slists + (size_t)2 * m : nullptr;
-    const int *bm_count = binned ? d_scounts + 2 : nullptr;
+    const int64_t nbm = binned ? sbin[SB_REST] : m;
+    const int *bm_rows = binned ? d_slists + (size_t)SB_REST * m : nullptr;
+    const int *bm_count = binned ? d_scounts + SB_REST : nullptr;
     int wpb = 4, waves_per_cu = 8;
     if (ldsbm) {
         int best = 0;
@@ -1954,18 +1962,18 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         }
         LAUNCH(c, "smm_symbolic", kern, sgrid, cw * 64, lds, (int)m, 1, bm_rows, bm_count, p->row_offset, cc.ws, cc.bm_words, (int)b->rows,
                (int64_t)a->nnz, cc.guard_chunk, a->ptr, a->idx, (const int *)cc.cptr, (const unsigned short *)cc.stream,
-               (const int64_t *)p->d_ub_off, (unsigned short *)p->d_tmp, p->d_P, p->d_rowcnt, d_rowctr + 2);
+               (const int64_t *)p->d_ub_off, (unsigned short *)p->d_tmp, p->d_P, p->d_rowcnt, d_rowctr + SB_REST);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "smm_symbolic_ccs: %s", hipGetErrorString(e)); }
     } else if (nbm > 0) {
         int sgrid = (int)std::min<int64_t>((nbm + wpb - 1) / wpb, (int64_t)c->n_cu * 8 * (4 / wpb));
         if (!ldsbm) PCHK(pool_get(c, (size_t)sgrid * wpb * (bm_words + 1), &gbm));
         const int mark = ldsbm ? MARK_LDS_BITMAP : MARK_GLOBAL_BITMAP;
-#define SYM_CASE(S, F, L) if (sym == S && safe == F && mark == L && !deep) PCHK((launch_symbolic_t<S, F, L>(c, p, bm_words, gbm, sgrid, wpb, bm_rows, bm_count, d_rowctr + 2)));
+#define SYM_CASE(S, F, L) if (sym == S && safe == F && mark == L && !deep) PCHK((launch_symbolic_t<S, F, L>(c, p, bm_words, gbm, sgrid, wpb, bm_rows, bm_count, d_rowctr + SB_REST)));
         SYM_CASE(false, false, MARK_LDS_BITMAP) SYM_CASE(false, true, MARK_LDS_BITMAP) SYM_CASE(true, false, MARK_LDS_BITMAP)
         SYM_CASE(true, true, MARK_LDS_BITMAP) SYM_CASE(false, false, MARK_GLOBAL_BITMAP) SYM_CASE(false, true, MARK_GLOBAL_BITMAP)
         SYM_CASE(true, false, MARK_GLOBAL_BITMAP) SYM_CASE(true, true, MARK_GLOBAL_BITMAP)
-#define SYM_DEEP(S, L) if (sym == S && mark == L && deep) PCHK((launch_symbolic_t<S, false, L, 32>(c, p, bm_words, gbm, sgrid, wpb, bm_rows, bm_count, d_rowctr + 2)));
+#define SYM_DEEP(S, L) if (sym == S && mark == L && deep) PCHK((launch_symbolic_t<S, false, L, 32>(c, p, bm_words, gbm, sgrid, wpb, bm_rows, bm_count, d_rowctr + SB_REST)));
         SYM_DEEP(false, MARK_LDS_BITMAP) SYM_DEEP(true, MARK_LDS_BITMAP) SYM_DEEP(false, MARK_GLOBAL_BITMAP) SYM_DEEP(true, MARK_GLOBAL_BITMAP)
 #undef SYM_DEEP
 #undef SYM_CASE
@@ -1983,10 +1991,11 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     if (p->nnz > 0) {
         // bin the rows of C: few nonzeros -> LDS hash kernels, the rest -> dense LDS tiles
         PCHK(pool_get(c, (size_t)4 * m, &p->d_lists));
-        int *d_counts = (int *)((char *)c->d_flags + 192);
-        hipError_t e = hipMemsetAsync(d_counts, 0, 4 * sizeof(int), c->stream);
-        LAUNCH(c, "smm_bin_rows", smm_bin_rows<int>, std::min<int64_t>((m + 1023) / 1024, 2048), 1024, 0, (int)m, c->hash_small,
-               c->hash_medium, (const int *)p->d_rowcnt, p->d_lists, d_counts, tiny_max, (const int64_t *)d_prod, a->ptr);
+        int *d_counts = (int *)((char *)c->d_flags + 320);
+        hipError_t e = hipMemsetAsync(d_counts, 0, 8 * sizeof(int), c->stream);
+        BinSpec nspec{2, {c->hash_small, c->hash_medium, 0, 0, 0, 0}, 3};
+        LAUNCH(c, "smm_bin_rows", smm_bin_rows<int>, std::min<int64_t>((m + 1023) / 1024, 2048), 1024, 0, (int)m, nspec,
+               (const int *)p->d_rowcnt, p->d_lists, d_counts, tiny_max, (const int64_t *)d_prod, a->ptr);
         if (e == hipSuccess) e = hipMemcpyAsync(p->n_bin, d_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         pool_free(c, d_prod);

@@ -830,7 +830,19 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, const int *__restrict
         // long, per-entry otherwise)
         if (MARK == MARK_GLOBAL_BITMAP) __threadfence();
         if (HASH) {
-            for (int w = lane; w < bm_words; w += WAVE) bm[w] = 0xffffffffu;
+            // (round 4) a row with few distinct columns empties the slots it filled instead of the whole set: every listed
+            // column is in the set, so its probe sequence ends at its slot whatever the other lanes have emptied meanwhile
+            // (an empty slot on the way does not stop it).  A band of half-width 8 puts 33 columns into 4096 slots.
+            if (n * 8 >= bm_words) {
+                for (int w = lane; w < bm_words; w += WAVE) bm[w] = 0xffffffffu;
+            } else {
+                for (int s2 = lane; s2 < n; s2 += WAVE) {
+                    const int cc = (int)out[s2];
+                    unsigned h = ((unsigned)cc * 0x9E3779B1u) >> hshift;
+                    for (unsigned tries = 0; tab[h] != cc && tries < hmask; ++tries) h = (h + 1) & hmask;
+                    tab[h] = -1;
+                }
+            }
         } else if (n >= bm_words) {
             for (int w = lane; w < bm_words; w += WAVE) bm[w] = 0;
         } else {
@@ -2037,35 +2049,41 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
 // Row binning after the symbolic phase: rows of C with few nonzeros go to the hash kernels
 // below, the rest to the dense-tile kernel above.  lists[b] receives the rows of bin b (order
 // irrelevant), counts[b] their number.  bin 0: 1..small_max, bin 1: ..med_max, bin 2: larger.
+struct BinSpec { int nb; int thr[6]; int tiny_bin; };   // bins 0 .. nb-1: 0 < n <= thr[b] (ascending); bin nb: the rest; tiny_bin: see below
 template <typename T>
-__global__ __launch_bounds__(1024) void smm_bin_rows(int m, int small_max, int med_max,
-                                                     const T *__restrict__ rowcnt,
+__global__ __launch_bounds__(1024) void smm_bin_rows(int m, const BinSpec spec, const T *__restrict__ rowcnt,
                                                      int *__restrict__ lists, int *__restrict__ counts,
                                                      int tiny_max = 0, const int64_t *__restrict__ tiny_ub = nullptr,
                                                      const int *__restrict__ a_ptr = nullptr)
 {
-    // bin 3 (round 4): TINY rows -- at most tiny_max products (tiny_ub) from at most tiny_max entries of A -- which the
-    // smm_*_tiny kernels handle several to a wave; the predicate does not depend on rowcnt, so the symbolic and the
-    // numeric binning put the same rows there.
-    __shared__ int wcnt[16][4], wbase[16][4];
+    // bin spec.tiny_bin (round 4): TINY rows -- at most tiny_max products (tiny_ub) from at most tiny_max entries of A --
+    // which the smm_*_tiny kernels handle several to a wave; the predicate does not depend on rowcnt, so the symbolic and
+    // the numeric binning put the same rows there.
+    constexpr int NBIN = 8;
+    __shared__ int wcnt[16][NBIN], wbase[16][NBIN];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     for (int base = blockIdx.x * 1024; base < m; base += gridDim.x * 1024) {        // workgroup-uniform trip count
         const int row = base + threadIdx.x;
         const T n = row < m ? rowcnt[row] : 0;
-        int b = n <= 0 ? -1 : (n <= small_max ? 0 : (n <= med_max ? 1 : 2));
+        int b = -1;
+        if (n > 0) {
+            b = spec.nb;
+#pragma unroll
+            for (int q = 5; q >= 0; --q) if (q < spec.nb && n <= (T)spec.thr[q]) b = q;
+        }
         if (tiny_max > 0 && row < m) {
             const int64_t u = tiny_ub[row];
-            if (u > 0 && u <= tiny_max && a_ptr[row + 1] - a_ptr[row] <= tiny_max) b = n > 0 ? 3 : -1;
+            if (u > 0 && u <= tiny_max && a_ptr[row + 1] - a_ptr[row] <= tiny_max) b = n > 0 ? spec.tiny_bin : -1;
         }
         unsigned long long mine = 0ull;
 #pragma unroll
-        for (int bin = 0; bin < 4; ++bin) {
+        for (int bin = 0; bin < NBIN; ++bin) {
             const unsigned long long mask = __ballot(b == bin);
             if (b == bin) mine = mask;
             if (lane == 0) wcnt[wave][bin] = (int)__popcll(mask);
         }
         __syncthreads();
-        if (threadIdx.x < 4) {                              // one atomic per workgroup and bin, not per row
+        if (threadIdx.x < NBIN) {                           // one atomic per workgroup and bin, not per row
             int total = 0;
             for (int w = 0; w < 16; ++w) total += wcnt[w][threadIdx.x];
             int at = total ? atomicAdd(&counts[threadIdx.x], total) : 0;
