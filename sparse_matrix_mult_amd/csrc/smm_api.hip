@@ -1160,6 +1160,15 @@ constexpr size_t LIST_SLACK = (size_t)1 << 17;      // entries behind the ordere
 #ifndef SMM_CCS_UNROLL
 #define SMM_CCS_UNROLL 8        // chunk loads in flight per wave of smm_symbolic_ccs (configs[1]: 2: 6.7, 4: 5.5, 8: 5.2 ms)
 #endif
+// the instantiation of the chunked symbolic walk: triangle, dense runs of columns in B, units per counter round trip
+using ccs_kernel_t = decltype(&smm_symbolic_ccs<false, SMM_CCS_UNROLL>);
+static ccs_kernel_t ccs_kernel(bool sym, bool dr, bool batch)
+{
+#define CCS_K(S, D, B) smm_symbolic_ccs<S, SMM_CCS_UNROLL, D, B>
+    if (batch) return dr ? (sym ? CCS_K(true, true, 16) : CCS_K(false, true, 16)) : (sym ? CCS_K(true, false, 16) : CCS_K(false, false, 16));
+    return dr ? (sym ? CCS_K(true, true, 1) : CCS_K(false, true, 1)) : (sym ? CCS_K(true, false, 1) : CCS_K(false, false, 1));
+#undef CCS_K
+}
 // ------------------------------------------------------------------------------ CSR x CSR -> CSR
 struct SlabGeom { int ws, n_slabs, rw; };
 constexpr int SLAB_NW = 8;                       // waves per workgroup of smm_dense_slab
@@ -1827,8 +1836,8 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
                 if (units >= INT32_MAX) { smm_plan_destroy(p); return fail(SMM_ERR_INVALID, "too many (slab, row) units"); }
                 const int sgrid = (int)std::min<int64_t>((units + cw - 1) / cw, (int64_t)c->n_cu * 8 * (4 / cw));
                 const bool dr = c->sym_dense == 2 || (c->sym_dense == 1 && cc.same_word >= 0.8);
-                auto kern = dr ? (sym ? smm_symbolic_ccs<true, SMM_CCS_UNROLL, true> : smm_symbolic_ccs<false, SMM_CCS_UNROLL, true>)
-                               : (sym ? smm_symbolic_ccs<true, SMM_CCS_UNROLL> : smm_symbolic_ccs<false, SMM_CCS_UNROLL>);
+                const bool batch = units >= (int64_t)64 * sgrid * cw && units < INT32_MAX - (1 << 24);          // many short units: 16 per counter round trip
+                auto kern = ccs_kernel(sym, dr, batch);
                 if (lds > 64 * 1024) {
                     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                     if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e)); }
@@ -1954,8 +1963,8 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         const size_t lds = wave_bytes * cw;
         const int sgrid = (int)std::min<int64_t>((nbm + cw - 1) / cw, (int64_t)c->n_cu * 8 * (4 / cw));
         const bool dr = c->sym_dense == 2 || (c->sym_dense == 1 && cc.same_word >= 0.8);
-        auto kern = dr ? (sym ? smm_symbolic_ccs<true, SMM_CCS_UNROLL, true> : smm_symbolic_ccs<false, SMM_CCS_UNROLL, true>)
-                       : (sym ? smm_symbolic_ccs<true, SMM_CCS_UNROLL> : smm_symbolic_ccs<false, SMM_CCS_UNROLL>);
+        const bool batch = nbm >= (int64_t)64 * sgrid * cw && nbm < INT32_MAX - (1 << 24);                // many short rows: 16 per counter round trip
+        auto kern = ccs_kernel(sym, dr, batch);
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e)); }

@@ -960,7 +960,13 @@ __global__ __launch_bounds__(256) void smm_ccs_row_work(int m, int n_slabs, int 
 // of a segmented OR over neighbouring lanes with the same word.  The ~15 extra vector instructions per chunk are what the
 // uniform-random walk cannot afford (profiles/r4_symbolic_lean.txt), hence a second instantiation, chosen from the
 // share of neighbouring entries of B that share a word (smm_ccs_fill).
-template <bool SYM, int UNROLL, bool DR = false>
+//
+// BATCH (round 4): units taken per counter round trip.  One atomic per unit on ONE word costs 11.4 ns of L2 time each -- a
+// tall-skinny product with 1e6 ten-entry rows spent 10.3 of its 11.45 ms symbolic phase there (1.18 ms with a static split,
+// diagnostic build).  The host picks 16 when there are at least 64 units per wave (imbalance then averages out) and 1
+// otherwise: as a template parameter, because any more scalar state in the BATCH = 1 loop spills into a walk that sits on the
+// issue corner (a guided, run-time batch size cost configs[1] 0.8 ms, profiles/r4_structured.txt).
+template <bool SYM, int UNROLL, bool DR = false, int BATCH = 1>
 __global__ __launch_bounds__(256) void smm_symbolic_ccs(int m, int n_slabs, const int *__restrict__ rowlist, const int *__restrict__ nrows_p,
                                                         int64_t row_offset, int ws, int bm_words, int rowsB, int64_t nnzA, int guard_chunk,
                                                         const int *__restrict__ a_ptr, const int *__restrict__ a_idx,
@@ -979,10 +985,11 @@ __global__ __launch_bounds__(256) void smm_symbolic_ccs(int m, int n_slabs, cons
     bm[bm_words + lane] = 0xffffffffu;                          // the guard words: one per lane
     const int guard = ccs_guard_col(bm_words, 2 * lane);        // this lane's guard column (never new)
     for (;;) {
-        int ui = 0;
-        if (lane == 0) ui = atomicAdd(unit_counter, 1);
-        ui = rl(ui, 0);
-        if (ui >= nunits) break;
+        int u0 = 0;
+        if (lane == 0) u0 = atomicAdd(unit_counter, BATCH);
+        u0 = rl(u0, 0);
+        if (u0 >= nunits) break;
+      for (int ui = u0; ui < u0 + BATCH && ui < nunits; ++ui) {
         const int s = ui / nrows;
         const int rr = ui - s * nrows;
         const int row = rowlist ? rowlist[rr] : rr;
@@ -1129,6 +1136,7 @@ __global__ __launch_bounds__(256) void smm_symbolic_ccs(int m, int n_slabs, cons
         } else {
             for (int s2 = lane; s2 < n; s2 += WAVE) bm[out[s2] >> 5] = 0;
         }
+      }
     }
 }
 

@@ -189,3 +189,20 @@ def test_short_rows_with_a_few_hubs(ctx, oracle):
                               np.concatenate(([0], np.diff(B.indptr)[A.indices].astype(np.int64).cumsum()))[A.indptr[:-1]])
     finally:
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_many_short_rows_take_units_sixteen_at_a_time(ctx, oracle, symmetric):
+    """600 000 rows with ~50 ... 400 products each against a narrow B: the chunked symbolic walk with 16 units per counter
+    round trip (>= 64 units per wave), same lists and counts as the oracle."""
+    rng = np.random.default_rng(31)
+    m, k = 600_000, 600
+    A = _rows(rng.integers(2, 9, m), k, rng)
+    B = _rows(rng.integers(20, 60, k), k if symmetric else 900, rng)
+    if symmetric:
+        A = sp.csr_matrix((A.data[:A.indptr[k]], A.indices[:A.indptr[k]], A.indptr[:k + 1]), shape=(k, k))       # square: 600 rows only
+        m = k
+    want = oracle.sparse(arrays(A), arrays(B), B.shape[1], symmetric=symmetric)
+    got, launches = _gpu(ctx, A, B, symmetric=symmetric, exact=True)
+    assert_csr_equal(got, want, values="bits")
+    assert launches["smm_symbolic"] >= 1
