@@ -1570,17 +1570,17 @@ static bool slab_pays(const smm_ctx *c, const smm_csr *a, const SlabGeom &g, dou
 
 template <bool SYM, bool SAFE, int MARK, int UNROLL, bool I16>
 static int launch_symbolic_w(smm_ctx *c, smm_plan *p, int words, unsigned *gbm, int grid, int wpb, const int *rowlist,
-                             const int *d_nrows, int *d_row_counter);
+                             const int *d_nrows, int *d_row_counter, int rbatch);
 template <bool SYM, bool SAFE, int MARK, int UNROLL = 16>
 static int launch_symbolic_t(smm_ctx *c, smm_plan *p, int words, unsigned *gbm, int grid, int wpb, const int *rowlist,
-                             const int *d_nrows, int *d_row_counter)
+                             const int *d_nrows, int *d_row_counter, int rbatch = 1)
 {
-    return p->list16 ? launch_symbolic_w<SYM, SAFE, MARK, UNROLL, true>(c, p, words, gbm, grid, wpb, rowlist, d_nrows, d_row_counter)
-                     : launch_symbolic_w<SYM, SAFE, MARK, UNROLL, false>(c, p, words, gbm, grid, wpb, rowlist, d_nrows, d_row_counter);
+    return p->list16 ? launch_symbolic_w<SYM, SAFE, MARK, UNROLL, true>(c, p, words, gbm, grid, wpb, rowlist, d_nrows, d_row_counter, rbatch)
+                     : launch_symbolic_w<SYM, SAFE, MARK, UNROLL, false>(c, p, words, gbm, grid, wpb, rowlist, d_nrows, d_row_counter, rbatch);
 }
 template <bool SYM, bool SAFE, int MARK, int UNROLL, bool I16>
 static int launch_symbolic_w(smm_ctx *c, smm_plan *p, int words, unsigned *gbm, int grid, int wpb, const int *rowlist,
-                             const int *d_nrows, int *d_row_counter)
+                             const int *d_nrows, int *d_row_counter, int rbatch)
 {
     // LDS per wave: bitmap words + the guard word, or the hash slots
     const size_t lds = MARK == MARK_GLOBAL_BITMAP ? 0 : (size_t)(words + (MARK == MARK_LDS_HASH ? 0 : 1)) * wpb * sizeof(unsigned);
@@ -1606,7 +1606,7 @@ static int launch_symbolic_w(smm_ctx *c, smm_plan *p, int words, unsigned *gbm, 
     LAUNCH(c, MARK == MARK_LDS_HASH ? "smm_symbolic_hash" : "smm_symbolic", kern, grid, wpb * 64, lds, (int)p->m, rowlist,
            d_nrows, p->row_offset, words, p->a->ptr, p->a->idx, p->b->ptr,
            I16 ? (const void *)p->b->idx16 : (const void *)b_idx32, p->d_ub_off, p->d_tmp, p->d_P,
-           p->d_rowcnt, gbm, d_row_counter);
+           p->d_rowcnt, gbm, d_row_counter, rbatch);
     LAUNCH_CHECK();
     return SMM_OK;
 }
@@ -1978,11 +1978,13 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         int sgrid = (int)std::min<int64_t>((nbm + wpb - 1) / wpb, (int64_t)c->n_cu * 8 * (4 / wpb));
         if (!ldsbm) PCHK(pool_get(c, (size_t)sgrid * wpb * (bm_words + 1), &gbm));
         const int mark = ldsbm ? MARK_LDS_BITMAP : MARK_GLOBAL_BITMAP;
-#define SYM_CASE(S, F, L) if (sym == S && safe == F && mark == L && !deep) PCHK((launch_symbolic_t<S, F, L>(c, p, bm_words, gbm, sgrid, wpb, bm_rows, bm_count, d_rowctr + SB_REST)));
+        // (round 4) many short rows: 16 per counter round trip (one atomic per row on one word is 11 ns of L2 time each)
+        const int rbatch = nbm >= (int64_t)64 * sgrid * wpb && nbm < INT32_MAX - (1 << 24) ? 16 : 1;
+#define SYM_CASE(S, F, L) if (sym == S && safe == F && mark == L && !deep) PCHK((launch_symbolic_t<S, F, L>(c, p, bm_words, gbm, sgrid, wpb, bm_rows, bm_count, d_rowctr + SB_REST, rbatch)));
         SYM_CASE(false, false, MARK_LDS_BITMAP) SYM_CASE(false, true, MARK_LDS_BITMAP) SYM_CASE(true, false, MARK_LDS_BITMAP)
         SYM_CASE(true, true, MARK_LDS_BITMAP) SYM_CASE(false, false, MARK_GLOBAL_BITMAP) SYM_CASE(false, true, MARK_GLOBAL_BITMAP)
         SYM_CASE(true, false, MARK_GLOBAL_BITMAP) SYM_CASE(true, true, MARK_GLOBAL_BITMAP)
-#define SYM_DEEP(S, L) if (sym == S && mark == L && deep) PCHK((launch_symbolic_t<S, false, L, 32>(c, p, bm_words, gbm, sgrid, wpb, bm_rows, bm_count, d_rowctr + SB_REST)));
+#define SYM_DEEP(S, L) if (sym == S && mark == L && deep) PCHK((launch_symbolic_t<S, false, L, 32>(c, p, bm_words, gbm, sgrid, wpb, bm_rows, bm_count, d_rowctr + SB_REST, rbatch)));
         SYM_DEEP(false, MARK_LDS_BITMAP) SYM_DEEP(true, MARK_LDS_BITMAP) SYM_DEEP(false, MARK_GLOBAL_BITMAP) SYM_DEEP(true, MARK_GLOBAL_BITMAP)
 #undef SYM_DEEP
 #undef SYM_CASE

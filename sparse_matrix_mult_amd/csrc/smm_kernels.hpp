@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, const int *__restrict
                                                     unsigned *__restrict__ P,
                                                     int *__restrict__ rowcnt,
                                                     unsigned *__restrict__ gbitmap,
-                                                    int *__restrict__ row_counter)
+                                                    int *__restrict__ row_counter, int rbatch)
 {
     extern __shared__ unsigned lds_bm[];
     using IT = std::conditional_t<I16, unsigned short, int>;
@@ -633,13 +633,17 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, const int *__restrict
     // cost 25 %), and rows differ in work anyway.  Every wave leaves when the counter passes the
     // last row.  Hash classes: the rows are tiny and there are up to 1e6 of them -- that many atomics
     // on one word cost more than they balance (measured), so those keep the interleaved static split.
+    // (round 4: rbatch rows per counter round trip -- 16 when the host sees >= 64 rows per wave, see smm_symbolic_ccs)
     for (int rs = blockIdx.x * wpb + wave;; rs += gridDim.x * wpb) {
-        int ri = rs;
+        int r0 = rs, r1 = rs + 1;
         if (!HASH) {
-            if (lane == 0) ri = atomicAdd(row_counter, 1);
-            ri = rl(ri, 0);
+            if (lane == 0) r0 = atomicAdd(row_counter, rbatch);
+            r0 = rl(r0, 0);
+            r1 = r0 + rbatch;
         }
-        if (ri >= nrows) break;
+        if (r0 >= nrows) break;
+        r1 = r1 < nrows ? r1 : nrows;
+      for (int ri = r0; ri < r1; ++ri) {
         const int row = rowlist ? rowlist[ri] : ri;
         const int a0 = a_ptr[row], a1 = a_ptr[row + 1];
         int thresh = 0;
@@ -849,6 +853,7 @@ __global__ __launch_bounds__(256) void smm_symbolic(int m, const int *__restrict
             for (int s2 = lane; s2 < n; s2 += WAVE) bm[out[s2] >> 5] = 0;
         }
         if (MARK == MARK_GLOBAL_BITMAP) __threadfence();
+      }
     }
 }
 

@@ -191,8 +191,9 @@ def test_short_rows_with_a_few_hubs(ctx, oracle):
         a.close(); b.close()
 
 
+@pytest.mark.parametrize("narrow", [True, False], ids=["chunked-walk", "plain-bitmap-walk"])
 @pytest.mark.parametrize("symmetric", [False, True])
-def test_many_short_rows_take_units_sixteen_at_a_time(ctx, oracle, symmetric):
+def test_many_short_rows_take_units_sixteen_at_a_time(ctx, oracle, symmetric, narrow):
     """600 000 rows with ~50 ... 400 products each against a narrow B: the chunked symbolic walk with 16 units per counter
     round trip (>= 64 units per wave), same lists and counts as the oracle."""
     rng = np.random.default_rng(31)
@@ -203,6 +204,10 @@ def test_many_short_rows_take_units_sixteen_at_a_time(ctx, oracle, symmetric):
         A = sp.csr_matrix((A.data[:A.indptr[k]], A.indices[:A.indptr[k]], A.indptr[:k + 1]), shape=(k, k))       # square: 600 rows only
         m = k
     want = oracle.sparse(arrays(A), arrays(B), B.shape[1], symmetric=symmetric)
-    got, launches = _gpu(ctx, A, B, symmetric=symmetric, exact=True)
+    ctx.tune_narrow(narrow)                                 # False: 32-bit lists -> the plain bitmap walk (smm_symbolic)
+    try:
+        got, launches = _gpu(ctx, A, B, symmetric=symmetric, exact=True)
+    finally:
+        ctx.tune_narrow(True)
     assert_csr_equal(got, want, values="bits")
     assert launches["smm_symbolic"] >= 1
