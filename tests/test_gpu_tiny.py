@@ -211,3 +211,26 @@ def test_many_short_rows_take_units_sixteen_at_a_time(ctx, oracle, symmetric, na
         ctx.tune_narrow(True)
     assert_csr_equal(got, want, values="bits")
     assert launches["smm_symbolic"] >= 1
+
+
+def test_tiny_rows_of_a_row_shard_keep_the_global_diagonal(ctx, oracle):
+    """Symmetric product of a row block (multi-GPU sharding: row_offset): the triangle test uses the global row index."""
+    rng = np.random.default_rng(37)
+    n = 4000
+    A = _rows(np.full(n, 3), n, rng)
+    B = _rows(rng.integers(0, 6, n), n, rng)
+    wp, wi, wv = oracle.sparse(arrays(A), arrays(B), n, symmetric=True)
+    b = ctx.csr_from_scipy(B)
+    try:
+        for r0, r1 in ((0, 1500), (1500, 1501), (1501, 4000)):
+            As = A[r0:r1]
+            a = ctx.csr_from_scipy(As)
+            try:
+                gp, gi, gv = ctx.spgemm_host(a, b, symmetric=True, row_offset=r0)
+            finally:
+                a.close()
+            assert np.array_equal(np.asarray(gp, np.int64), np.asarray(wp[r0:r1 + 1], np.int64) - int(wp[r0]))
+            assert np.array_equal(gi, wi[wp[r0]:wp[r1]])
+            assert np.array_equal(gv.view(np.int64), wv[wp[r0]:wp[r1]].view(np.int64))
+    finally:
+        b.close()
