@@ -12,12 +12,15 @@
 //    values to rounding).  SMM_EXACT: every wave owns a contiguous "fine tile" of it and walks the
 //    row's A entries in stored order, so each accumulator receives its products in exactly the
 //    reference's order (one wave's LDS atomics execute in issue order): values are bit-identical
-//    to the CPU loop.  Rows with few nonzeros take LDS hash kernels instead of tiles.
+//    to the CPU loop.  Rows with few nonzeros take LDS hash kernels instead of tiles; rows with at most 16
+//    products go four to a wave with no marker at all (smm_symbolic_tiny / smm_numeric_tiny, round 4).
 //  * The first-touch column order of the reference is produced by smm_symbolic:
 //    one wave per row, a marker of B's columns in LDS (bitmap, or a hash set for rows with few
 //    products on wide matrices), test-and-set + ballot/mbcnt ordered compaction.  The numeric
 //    kernel then emits indices/values in that order straight from the tile it has just
-//    accumulated, as contiguous sub-runs (smm_runs).
+//    accumulated, as contiguous sub-runs (smm_runs).  Sorted operands take the walk over a chunk-padded
+//    16-bit column stream (smm_symbolic_ccs), with a second instantiation for operands with dense runs
+//    of columns (plain reads + merged ORs instead of same-word returning atomics).
 //  * No MFMA anywhere: this is an indexing / HBM path.
 #pragma once
 #include <hip/hip_runtime.h>
