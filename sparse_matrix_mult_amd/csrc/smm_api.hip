@@ -1200,8 +1200,8 @@ struct smm_plan {
     smm_csr::SlabCache slab{0, 0, nullptr, nullptr, nullptr};
     int *d_rowcnt = nullptr;       // m
     int64_t total_cap = 0;         // sum of the list capacities (= d_ub_off's last entry)
-    int *d_lists = nullptr;        // 4 x m: rows of the small / medium / dense / tiny bins
-    int n_bin[4] = {0, 0, 0, 0};
+    int *d_lists = nullptr;        // 5 x m: rows of the small / medium / dense / tiny (16) / tiny (32) bins
+    int n_bin[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t *d_cptr = nullptr;     // m+1
 };
 
@@ -1747,7 +1747,7 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     int hmax[NHC];
     for (int i = 0; i < NHC; ++i) hmax[i] = (!safe && bm_bytes > (size_t)HS[i] * 4) ? HS[i] / 2 : (i ? hmax[i - 1] : 0);
     const int hmax1 = hmax[NHC - 1];
-    constexpr int SB_REST = NHC, SB_TINY = NHC + 1, SB_N = NHC + 2;      // bins of the symbolic phase: hash classes, bitmap, tiny
+    constexpr int SB_REST = NHC, SB_TINY = NHC + 1, SB_TINY2 = NHC + 2, SB_N = NHC + 3;      // bins of the symbolic phase: hash classes, bitmap, tiny (16 / 32 lanes per row)
     // ... and TINY rows (<= 16 products from <= 16 entries of A, whatever B looks like) go four to a wave (smm_symbolic_tiny)
     const int tiny_max = c->tiny_max;
     const bool binned = hmax1 > 0 || tiny_max > 0;
@@ -1759,7 +1759,7 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         PCHK(pool_get(c, (size_t)SB_N * m, &d_slists));
         hipError_t e = hipMemsetAsync(d_scounts, 0, 8 * sizeof(int), c->stream);
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "memset: %s", hipGetErrorString(e)); }
-        BinSpec spec{NHC, {hmax[0], hmax[1], hmax[2], hmax[3], 0, 0}, SB_TINY};
+        BinSpec spec{NHC, {hmax[0], hmax[1], hmax[2], hmax[3], 0, 0}, SB_TINY, SB_TINY2};
         LAUNCH(c, "smm_bin_rows", smm_bin_rows<int64_t>, std::min<int64_t>((m + 1023) / 1024, 2048), 1024, 0, (int)m, spec,
                (const int64_t *)d_ub, d_slists, d_scounts, tiny_max, (const int64_t *)d_prod, a->ptr);
     }
@@ -1857,13 +1857,13 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
             }
             if (p->nnz > 0) {
                 // every non-empty row goes to the tile kernel (the hash kernels read one list per row)
-                PCHK(pool_get(c, (size_t)4 * m, &p->d_lists));
+                PCHK(pool_get(c, (size_t)5 * m, &p->d_lists));
                 int *d_counts = (int *)((char *)c->d_flags + 320);
                 hipError_t e = hipMemsetAsync(d_counts, 0, 8 * sizeof(int), c->stream);
-                BinSpec nspec{2, {0, 0, 0, 0, 0, 0}, 3};
+                BinSpec nspec{2, {0, 0, 0, 0, 0, 0}, 3, 4};
                 LAUNCH(c, "smm_bin_rows", smm_bin_rows<int>, std::min<int64_t>((m + 1023) / 1024, 2048), 1024, 0, (int)m, nspec,
                        (const int *)p->d_rowcnt, p->d_lists, d_counts);
-                if (e == hipSuccess) e = hipMemcpyAsync(p->n_bin, d_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(p->n_bin, d_counts, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
                 if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "row binning: %s", hipGetErrorString(e)); }
             }
@@ -1911,15 +1911,21 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         hipError_t e = hipMemsetAsync(d_rowctr, 0, 8 * sizeof(int), c->stream);
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "memset: %s", hipGetErrorString(e)); }
     }
-    // tiny rows: four to a wave, no marker at all
-    if (sbin[SB_TINY] > 0) {
-        const int tgrid = (int)std::min<int64_t>(((int64_t)sbin[SB_TINY] + 15) / 16, (int64_t)c->n_cu * 32);
-        const int *rows3 = d_slists + (size_t)SB_TINY * m;
-#define TINY_CASE(S, IT)                                                                                                        \
-        LAUNCH(c, "smm_symbolic_tiny", (smm_symbolic_tiny<S, IT>), tgrid, 256, 0, sbin[SB_TINY], rows3, p->row_offset, a->ptr, a->idx,  \
+    // tiny rows: four (<= 16 products) or two (<= 32) to a wave, no marker at all
+    for (int tc = 0; tc < 2; ++tc) {
+        const int bin = tc == 0 ? SB_TINY : SB_TINY2;
+        const int nt = sbin[bin];
+        if (nt == 0) continue;
+        const int per_wg = tc == 0 ? 16 : 8;                         // rows per 256-thread workgroup
+        const int tgrid = (int)std::min<int64_t>(((int64_t)nt + per_wg - 1) / per_wg, (int64_t)c->n_cu * 32);
+        const int *rows3 = d_slists + (size_t)bin * m;
+#define TINY_CASE(S, IT, G)                                                                                                      \
+        LAUNCH(c, "smm_symbolic_tiny", (smm_symbolic_tiny<S, IT, G>), tgrid, 256, 0, nt, rows3, p->row_offset, a->ptr, a->idx,     \
                b->ptr, b->idx, (const int64_t *)p->d_ub_off, (IT *)p->d_tmp, p->d_P, p->d_rowcnt, c->d_err);
-        if (p->list16) { if (sym) { TINY_CASE(true, unsigned short) } else { TINY_CASE(false, unsigned short) } }
-        else           { if (sym) { TINY_CASE(true, int) } else { TINY_CASE(false, int) } }
+#define TINY_G_CASE(S, IT) if (tc == 0) { TINY_CASE(S, IT, TINY_G) } else { TINY_CASE(S, IT, TINY_G2) }
+        if (p->list16) { if (sym) { TINY_G_CASE(true, unsigned short) } else { TINY_G_CASE(false, unsigned short) } }
+        else           { if (sym) { TINY_G_CASE(true, int) } else { TINY_G_CASE(false, int) } }
+#undef TINY_G_CASE
 #undef TINY_CASE
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "smm_symbolic_tiny: %s", hipGetErrorString(e)); }
@@ -2001,13 +2007,13 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
     if (p->nnz <= 0) pool_free(c, d_prod);
     if (p->nnz > 0) {
         // bin the rows of C: few nonzeros -> LDS hash kernels, the rest -> dense LDS tiles
-        PCHK(pool_get(c, (size_t)4 * m, &p->d_lists));
+        PCHK(pool_get(c, (size_t)5 * m, &p->d_lists));
         int *d_counts = (int *)((char *)c->d_flags + 320);
         hipError_t e = hipMemsetAsync(d_counts, 0, 8 * sizeof(int), c->stream);
-        BinSpec nspec{2, {c->hash_small, c->hash_medium, 0, 0, 0, 0}, 3};
+        BinSpec nspec{2, {c->hash_small, c->hash_medium, 0, 0, 0, 0}, 3, 4};
         LAUNCH(c, "smm_bin_rows", smm_bin_rows<int>, std::min<int64_t>((m + 1023) / 1024, 2048), 1024, 0, (int)m, nspec,
                (const int *)p->d_rowcnt, p->d_lists, d_counts, tiny_max, (const int64_t *)d_prod, a->ptr);
-        if (e == hipSuccess) e = hipMemcpyAsync(p->n_bin, d_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(p->n_bin, d_counts, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         pool_free(c, d_prod);
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "row binning: %s", hipGetErrorString(e)); }
@@ -2090,15 +2096,18 @@ extern "C" int smm_spgemm_numeric(smm_ctx *c, smm_plan *p, int64_t *d_c_indptr, 
         }
         LAUNCH_CHECK();
     }
-    // tiny rows: four to a wave, first touch found among the lanes (always the reference's order of additions)
-    if (p->n_bin[3] > 0) {
-        const int nt = p->n_bin[3];
-        const int tgrid = (int)std::min<int64_t>(((int64_t)nt + 15) / 16, (int64_t)c->n_cu * 32);
-        const int *rows3 = p->d_lists + 3 * m;
-        if (sym) LAUNCH(c, "smm_numeric_tiny", smm_numeric_tiny<true>, tgrid, 256, 0, nt, rows3, p->row_offset, p->a->ptr, p->a->idx, p->a->val,
-                        p->b->ptr, p->b->idx, p->b->val, (const int64_t *)p->d_cptr, d_c_indices, d_c_data, c->d_err);
-        else     LAUNCH(c, "smm_numeric_tiny", smm_numeric_tiny<false>, tgrid, 256, 0, nt, rows3, p->row_offset, p->a->ptr, p->a->idx, p->a->val,
-                        p->b->ptr, p->b->idx, p->b->val, (const int64_t *)p->d_cptr, d_c_indices, d_c_data, c->d_err);
+    // tiny rows: four / two to a wave, first touch found among the lanes (always the reference's order of additions)
+    for (int tc = 0; tc < 2; ++tc) {
+        const int nt = p->n_bin[3 + tc];
+        if (nt == 0) continue;
+        const int per_wg = tc == 0 ? 16 : 8;
+        const int tgrid = (int)std::min<int64_t>(((int64_t)nt + per_wg - 1) / per_wg, (int64_t)c->n_cu * 32);
+        const int *rows3 = p->d_lists + (size_t)(3 + tc) * m;
+#define TINY_NUM(S, G) LAUNCH(c, "smm_numeric_tiny", (smm_numeric_tiny<S, G>), tgrid, 256, 0, nt, rows3, p->row_offset, p->a->ptr, p->a->idx, \
+                              p->a->val, p->b->ptr, p->b->idx, p->b->val, (const int64_t *)p->d_cptr, d_c_indices, d_c_data, c->d_err)
+        if (tc == 0) { if (sym) TINY_NUM(true, TINY_G); else TINY_NUM(false, TINY_G); }
+        else         { if (sym) TINY_NUM(true, TINY_G2); else TINY_NUM(false, TINY_G2); }
+#undef TINY_NUM
         LAUNCH_CHECK();
     }
     if (p->n_bin[2] == 0) return SMM_OK;

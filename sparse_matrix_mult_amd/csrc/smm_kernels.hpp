@@ -2065,16 +2065,16 @@ __global__ __launch_bounds__(NW * 64) void smm_numeric(const NumericArgs A)
 // Row binning after the symbolic phase: rows of C with few nonzeros go to the hash kernels
 // below, the rest to the dense-tile kernel above.  lists[b] receives the rows of bin b (order
 // irrelevant), counts[b] their number.  bin 0: 1..small_max, bin 1: ..med_max, bin 2: larger.
-struct BinSpec { int nb; int thr[6]; int tiny_bin; };   // bins 0 .. nb-1: 0 < n <= thr[b] (ascending); bin nb: the rest; tiny_bin: see below
+struct BinSpec { int nb; int thr[6]; int tiny_bin, tiny_bin2; };   // bins 0 .. nb-1: 0 < n <= thr[b] (ascending); bin nb: the rest; tiny bins: see below
 template <typename T>
 __global__ __launch_bounds__(1024) void smm_bin_rows(int m, const BinSpec spec, const T *__restrict__ rowcnt,
                                                      int *__restrict__ lists, int *__restrict__ counts,
                                                      int tiny_max = 0, const int64_t *__restrict__ tiny_ub = nullptr,
                                                      const int *__restrict__ a_ptr = nullptr)
 {
-    // bin spec.tiny_bin (round 4): TINY rows -- at most tiny_max products (tiny_ub) from at most tiny_max entries of A --
-    // which the smm_*_tiny kernels handle several to a wave; the predicate does not depend on rowcnt, so the symbolic and
-    // the numeric binning put the same rows there.
+    // bins spec.tiny_bin / tiny_bin2 (round 4): TINY rows -- at most tiny_max (2 x tiny_max) products (tiny_ub) from at most
+    // as many entries of A -- which the smm_*_tiny kernels handle four (two) to a wave; the predicate does not depend on
+    // rowcnt, so the symbolic and the numeric binning put the same rows there.
     constexpr int NBIN = 8;
     __shared__ int wcnt[16][NBIN], wbase[16][NBIN];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -2089,7 +2089,9 @@ __global__ __launch_bounds__(1024) void smm_bin_rows(int m, const BinSpec spec, 
         }
         if (tiny_max > 0 && row < m) {
             const int64_t u = tiny_ub[row];
-            if (u > 0 && u <= tiny_max && a_ptr[row + 1] - a_ptr[row] <= tiny_max) b = n > 0 ? spec.tiny_bin : -1;
+            const int na = a_ptr[row + 1] - a_ptr[row];
+            if (u > 0 && u <= tiny_max && na <= tiny_max) b = n > 0 ? spec.tiny_bin : -1;
+            else if (u > 0 && u <= 2 * tiny_max && na <= 2 * tiny_max) b = n > 0 ? spec.tiny_bin2 : -1;
         }
         unsigned long long mine = 0ull;
 #pragma unroll
@@ -2112,7 +2114,8 @@ __global__ __launch_bounds__(1024) void smm_bin_rows(int m, const BinSpec spec, 
 }
 
 // ---------------------------------------------------------------------------------------
-// TINY rows (round 4): at most G products from at most G entries of A, G = 16 lanes per row, four rows per wave.
+// TINY rows (round 4): at most G products from at most G entries of A; G = 16 lanes per row (four rows per wave) for up to
+// 16 products, G = 32 (two rows per wave) for 17 ... 32.
 // The hash kernels give every row a whole wave and a chain of ~5 dependent loads with ONE row in flight per wave: at
 // 4 entries per row 3 % of the lanes work (30 M rows x 2 entries: 35 + 33 ms).  Here lane p of a row's group IS
 // product p (entries of A in order, inside each the row of B in order -- the reference's loop order,
@@ -2121,34 +2124,37 @@ __global__ __launch_bounds__(1024) void smm_bin_rows(int m, const BinSpec spec, 
 // the numeric kernel adds the later lanes of the same column to the first one in ascending order -- the reference's
 // order of additions, bit for bit.  B may be unsorted and may repeat columns (the earliest product wins, as in the
 // reference).  SYM: columns left of the diagonal are dropped (sparsework.cpp:160-167).
-constexpr int TINY_G = 16;
+constexpr int TINY_G = 16;         // lanes per row of the first tiny class (one DPP row); the second class takes 32 (two DPP rows)
+constexpr int TINY_G2 = 32;
 struct TinyMap { int col; int k; int e; bool valid; int nprod; int excl; };
-template <bool SYM>
+template <bool SYM, int G>
 __device__ __forceinline__ TinyMap tiny_map(const int row, const bool have, const int64_t row_offset, const int pl,
                                             const int gbase, const int *__restrict__ a_ptr, const int *__restrict__ a_idx,
                                             const int *__restrict__ b_ptr, const int *__restrict__ b_idx)
 {
+    static_assert(G == 16 || G == 32, "one or two DPP rows per group");
     // entry lanes: lane i of the group holds entry a0 + i (bs, len); product lanes: lane p holds product p
     const int a0 = have ? a_ptr[row] : 0;
     const int na = have ? a_ptr[row + 1] - a0 : 0;
-    const bool ev = pl < na && pl < TINY_G;
+    const bool ev = pl < na;
     const int r = ev ? a_idx[a0 + pl] : 0;
     const int bs = ev ? b_ptr[r] : 0;
     int len = ev ? b_ptr[r + 1] - bs : 0;
-    len = len < 0 ? 0 : (len > TINY_G ? TINY_G + 1 : len);        // (a row beyond the class never gets here; clamped all the same)
-    // inclusive scan inside the 16-lane row
+    len = len < 0 ? 0 : (len > G ? G + 1 : len);               // (a row beyond the class never gets here; clamped all the same)
+    // inclusive scan inside the group: the 16-lane row, then (G = 32) lane 15 of the even row into the odd row
     int incl = len;
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);
+    if constexpr (G == 32) incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
     const int excl = incl - len;
-    int nprod = __shfl(incl, gbase + TINY_G - 1);
-    nprod = (nprod > TINY_G || na > TINY_G) ? -1 : nprod;       // (never: the class holds rows with <= G products from <= G entries; reported)
+    int nprod = __shfl(incl, gbase + G - 1);
+    nprod = (nprod > G || na > G) ? -1 : nprod;                 // (never: the class holds rows with <= G products from <= G entries; reported)
     // product p = pl: its entry is the number of entries that end at or before p
     int ej = 0;
 #pragma unroll
-    for (int sft = TINY_G / 2; sft > 0; sft >>= 1)
+    for (int sft = G / 2; sft > 0; sft >>= 1)
         if (__shfl(incl, gbase + ej + sft - 1) <= pl) ej += sft;
     const int e_bs = __shfl(bs, gbase + ej), e_ex = __shfl(excl, gbase + ej);
     TinyMap t;
@@ -2161,59 +2167,76 @@ __device__ __forceinline__ TinyMap tiny_map(const int row, const bool have, cons
     t.excl = excl;
     return t;
 }
-// dist = how many lanes back the FIRST lane with this lane's column sits (0: this lane is the first)
+// dup = an EARLIER lane of the group carries this lane's column: lanes before it in its own 16-lane row (DPP row_shr), and
+// (G = 32) for the lanes of the odd row every lane of the even row (ds_bpermute: no DPP form crosses rows by a distance)
 template <int D>
-__device__ __forceinline__ void tiny_first(const int col, const int pl, int &dist)
+__device__ __forceinline__ void tiny_first_row(const int col, const int pl16, bool &dup)
 {
-    if constexpr (D < TINY_G) {
+    if constexpr (D < 16) {
         const int prev = __builtin_amdgcn_update_dpp(-2, col, 0x110 + D, 0xf, 0xf, false);      // row_shr:D (lanes shifted in keep -2)
-        if (pl >= D && prev == col) dist = D;
-        tiny_first<D + 1>(col, pl, dist);
+        if (pl16 >= D && prev == col) dup = true;
+        tiny_first_row<D + 1>(col, pl16, dup);
     }
 }
-template <bool SYM, typename IT>
+template <int G>
+__device__ __forceinline__ bool tiny_dup(const int col, const int pl, const int gbase)
+{
+    bool dup = false;
+    tiny_first_row<1>(col, pl & 15, dup);
+    if constexpr (G == 32) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int other = __shfl(col, gbase + j);
+            if (pl >= 16 && other == col) dup = true;
+        }
+    }
+    return dup;
+}
+template <bool SYM, typename IT, int G>
 __global__ __launch_bounds__(256) void smm_symbolic_tiny(int nrows, const int *__restrict__ rowlist, int64_t row_offset,
                                                          const int *__restrict__ a_ptr, const int *__restrict__ a_idx,
                                                          const int *__restrict__ b_ptr, const int *__restrict__ b_idx,
                                                          const int64_t *__restrict__ ub_off, IT *__restrict__ tmp_idx,
                                                          unsigned *__restrict__ P, int *__restrict__ rowcnt, unsigned *__restrict__ err)
 {
-    constexpr int RW = WAVE / TINY_G;                           // rows per wave
-    const int lane = lane_id(), pl = lane & (TINY_G - 1), g = lane / TINY_G, gbase = g * TINY_G;
+    constexpr int RW = WAVE / G;                                // rows per wave
+    constexpr unsigned GMASK = G == 32 ? 0xffffffffu : 0xffffu;
+    const int lane = lane_id(), pl = lane & (G - 1), g = lane / G, gbase = g * G;
     const int wave = (int)(threadIdx.x >> 6), wpb = blockDim.x / WAVE;
     for (int rb = (blockIdx.x * wpb + wave) * RW; rb < nrows; rb += gridDim.x * wpb * RW) {       // wave-uniform
         const int ri = rb + g;
         const bool have = ri < nrows;
         const int row = have ? rowlist[ri] : 0;
-        const TinyMap t = tiny_map<SYM>(row, have, row_offset, pl, gbase, a_ptr, a_idx, b_ptr, b_idx);
-        int dist = 0;
-        tiny_first<1>(t.col, pl, dist);
-        const bool isnew = t.valid && dist == 0;
-        const unsigned gm = (unsigned)(__ballot(isnew) >> gbase) & ((1u << TINY_G) - 1u);
+        const TinyMap t = tiny_map<SYM, G>(row, have, row_offset, pl, gbase, a_ptr, a_idx, b_ptr, b_idx);
+        const bool isnew = t.valid && !tiny_dup<G>(t.col, pl, gbase);
+        const unsigned gm = (unsigned)(__ballot(isnew) >> gbase) & GMASK;
+        const unsigned below = pl ? (0xffffffffu >> (32 - pl)) : 0u;                    // lanes of the group before this one
         if (have && t.nprod < 0) { if (pl == 0) { plan_err(err, PLAN_ERR_COUNT, row); rowcnt[row] = 0; } }
         else if (have) {
-            if (isnew) tmp_idx[ub_off[row] + __popc(gm & ((1u << pl) - 1u))] = (IT)t.col;
+            if (isnew) tmp_idx[ub_off[row] + __popc(gm & below)] = (IT)t.col;
             if (pl == 0) rowcnt[row] = __popc(gm);
             // start slots: the list length when step e starts = new products before the entry's first product
             const int na = a_ptr[row + 1] - a_ptr[row];
-            if (pl < na) P[a_ptr[row] + pl] = (unsigned)__popc(gm & ((1u << (t.excl < TINY_G ? t.excl : TINY_G)) - 1u));
+            const int ex = t.excl < G ? t.excl : G;
+            if (pl < na) P[a_ptr[row] + pl] = (unsigned)__popc(gm & (ex ? (0xffffffffu >> (32 - ex)) : 0u));
         }
     }
 }
+// the first lane of a column adds the later lanes of that column in ascending lane order = the reference's order of additions
 template <int D>
-__device__ __forceinline__ void tiny_gather(const int col, const int pl, const bool valid, const double v, double &sum)
+__device__ __forceinline__ void tiny_gather_row(const int col, const int pl16, const bool lead, const double v, double &sum)
 {
-    if constexpr (D < TINY_G) {
-        const int nc = __builtin_amdgcn_update_dpp(-2, col, 0x100 + D, 0xf, 0xf, false);         // row_shl:D: lane pl + D
+    if constexpr (D < 16) {
+        const int nc = __builtin_amdgcn_update_dpp(-2, col, 0x100 + D, 0xf, 0xf, false);         // row_shl:D: lane pl + D of the row
         const unsigned long long vb = __builtin_bit_cast(unsigned long long, v);
         const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)vb, 0x100 + D, 0xf, 0xf, false);
         const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(vb >> 32), 0x100 + D, 0xf, 0xf, false);
         const double nv = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-        if (valid && pl + D < TINY_G && nc == col) sum = sum + nv;
-        tiny_gather<D + 1>(col, pl, valid, v, sum);
+        if (lead && pl16 + D < 16 && nc == col) sum = sum + nv;
+        tiny_gather_row<D + 1>(col, pl16, lead, v, sum);
     }
 }
-template <bool SYM>
+template <bool SYM, int G>
 __global__ __launch_bounds__(256) void smm_numeric_tiny(int nrows, const int *__restrict__ rowlist, int64_t row_offset,
                                                         const int *__restrict__ a_ptr, const int *__restrict__ a_idx,
                                                         const double *__restrict__ a_val, const int *__restrict__ b_ptr,
@@ -2221,28 +2244,38 @@ __global__ __launch_bounds__(256) void smm_numeric_tiny(int nrows, const int *__
                                                         const int64_t *__restrict__ c_ptr, int *__restrict__ c_idx,
                                                         double *__restrict__ c_val, unsigned *__restrict__ err)
 {
-    constexpr int RW = WAVE / TINY_G;
-    const int lane = lane_id(), pl = lane & (TINY_G - 1), g = lane / TINY_G, gbase = g * TINY_G;
+    constexpr int RW = WAVE / G;
+    constexpr unsigned GMASK = G == 32 ? 0xffffffffu : 0xffffu;
+    const int lane = lane_id(), pl = lane & (G - 1), g = lane / G, gbase = g * G;
     const int wave = (int)(threadIdx.x >> 6), wpb = blockDim.x / WAVE;
     for (int rb = (blockIdx.x * wpb + wave) * RW; rb < nrows; rb += gridDim.x * wpb * RW) {
         const int ri = rb + g;
         const bool have = ri < nrows;
         const int row = have ? rowlist[ri] : 0;
-        const TinyMap t = tiny_map<SYM>(row, have, row_offset, pl, gbase, a_ptr, a_idx, b_ptr, b_idx);
+        const TinyMap t = tiny_map<SYM, G>(row, have, row_offset, pl, gbase, a_ptr, a_idx, b_ptr, b_idx);
         const double v = t.valid ? a_val[t.e] * b_val[t.k] : 0.0;
-        int dist = 0;
-        tiny_first<1>(t.col, pl, dist);
-        const bool isnew = t.valid && dist == 0;
+        const bool isnew = t.valid && !tiny_dup<G>(t.col, pl, gbase);
         double sum = v;                                         // `values[index] = p` (sparsework.cpp:108), then += in product order
-        tiny_gather<1>(t.col, pl, isnew, v, sum);
-        const unsigned gm = (unsigned)(__ballot(isnew) >> gbase) & ((1u << TINY_G) - 1u);
+        tiny_gather_row<1>(t.col, pl & 15, isnew, v, sum);      // the later lanes of its own 16-lane row ...
+        if constexpr (G == 32) {                                // ... then, for a first lane in the even row, the odd row in lane order
+            const unsigned long long vb = __builtin_bit_cast(unsigned long long, v);
+#pragma unroll
+            for (int j = 16; j < 32; ++j) {
+                const int oc = __shfl(t.col, gbase + j);
+                const unsigned lo = (unsigned)__shfl((int)(unsigned)vb, gbase + j), hi = (unsigned)__shfl((int)(unsigned)(vb >> 32), gbase + j);
+                const double ov = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+                if (isnew && pl < 16 && oc == t.col) sum = sum + ov;
+            }
+        }
+        const unsigned gm = (unsigned)(__ballot(isnew) >> gbase) & GMASK;
+        const unsigned below = pl ? (0xffffffffu >> (32 - pl)) : 0u;
         if (have) {
             const int64_t rs = c_ptr[row];
             // (always on: the symbolic phase counted this row with the same map -- a different count would put stores
             // into the neighbouring rows)
             if ((int64_t)__popc(gm) != c_ptr[row + 1] - rs) { if (pl == 0) plan_err(err, PLAN_ERR_COUNT, row); }
             else if (isnew) {
-                const int64_t at = rs + __popc(gm & ((1u << pl) - 1u));
+                const int64_t at = rs + __popc(gm & below);
                 c_idx[at] = t.col;
                 c_val[at] = sum;
             }

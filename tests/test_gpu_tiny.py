@@ -45,15 +45,17 @@ def _gpu(ctx, A, B, **kw):
 
 @pytest.mark.parametrize("exact", [False, True])
 @pytest.mark.parametrize("symmetric", [False, True])
-@pytest.mark.parametrize("n,per_row", [(40, 2), (3000, 3), (100_000, 4), (70_000, 1)])
+@pytest.mark.parametrize("n,per_row", [(40, 2), (3000, 3), (100_000, 4), (70_000, 1), (50_000, 5), (9000, 8), (20_000, 31)])
 def test_every_row_tiny(ctx, oracle, n, per_row, symmetric, exact):
+    """per_row <= 4: at most 16 products (16 lanes per row); 5, 8, 31: at most 32 (32 lanes per row, two DPP rows)."""
     rng = np.random.default_rng(n + per_row)
     A = _rows(np.full(n, per_row), n, rng)
-    B = _rows(rng.integers(0, min(per_row + 2, 16 // per_row + 1), n), n, rng)      # some rows of B empty; <= 16 products per row
+    cap = 16 if per_row <= 4 else 32
+    B = _rows(rng.integers(0, min(per_row + 2, cap // per_row + 1), n), n, rng)     # some rows of B empty; <= cap products per row
     want = oracle.sparse(arrays(A), arrays(B), n, symmetric=symmetric)
     got, launches = _gpu(ctx, A, B, symmetric=symmetric, exact=exact)
     assert_csr_equal(got, want, values="bits")
-    assert launches["smm_symbolic_tiny"] == 1 and launches["smm_numeric_tiny"] == 1
+    assert 1 <= launches["smm_symbolic_tiny"] <= 2 and launches["smm_numeric_tiny"] == launches["smm_symbolic_tiny"]
     assert launches["smm_symbolic_hash"] == 0 and launches["smm_numeric_hash"] == 0 and launches["smm_numeric"] == 0
 
 
@@ -83,9 +85,9 @@ def test_rows_around_the_class_limit(ctx, oracle, symmetric, exact):
     want = oracle.sparse(arrays(A), arrays(B), n, symmetric=symmetric)
     got, launches = _gpu(ctx, A, B, symmetric=symmetric, exact=exact)
     assert_csr_equal(got, want, values="bits" if exact else "tol")
-    assert launches["smm_symbolic_tiny"] == 1 and launches["smm_numeric_tiny"] == 1
+    assert launches["smm_symbolic_tiny"] == 2 and launches["smm_numeric_tiny"] == 2       # the 16-lane and the 32-lane class
     # the tiny rows alone, value for value (they are added in the reference's order in both modes)
-    tiny = np.flatnonzero((prods <= 16) & (np.diff(A.indptr) <= 16))
+    tiny = np.flatnonzero((prods <= 32) & (np.diff(A.indptr) <= 32))
     gp, gi, gv = got
     wp, wi, wv = want
     for r in tiny:
@@ -98,7 +100,7 @@ def test_tiny_rows_of_an_unsorted_operand_with_repeated_columns(ctx, oracle, exa
     rng = np.random.default_rng(11)
     n = 2000
     A = _rows(np.full(n, 3), n, rng)
-    lens = rng.integers(1, 5, n)
+    lens = rng.integers(1, 11, n)                               # up to 30 products: both tiny classes
     indptr = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
     cols = np.concatenate([rng.integers(0, 6, int(k)) + int(rng.integers(0, n - 6)) for k in lens]).astype(np.int32)   # repeats likely
     B = sp.csr_matrix((rng.uniform(-1, 1, int(indptr[-1])), cols, indptr), shape=(n, n))
@@ -107,7 +109,7 @@ def test_tiny_rows_of_an_unsorted_operand_with_repeated_columns(ctx, oracle, exa
     want = oracle.sparse(arrays(A), arrays(B), n)
     got, launches = _gpu(ctx, A, B, exact=exact)
     assert_csr_equal(got, want, values="bits")
-    assert launches["smm_symbolic_tiny"] == 1 and launches["smm_numeric_tiny"] == 1
+    assert launches["smm_symbolic_tiny"] == 2 and launches["smm_numeric_tiny"] == 2
 
 
 def test_tiny_rows_next_to_long_rows_and_new_values_on_the_same_plan(ctx, oracle):
