@@ -2038,12 +2038,13 @@ extern "C" int smm_spgemm_symbolic(smm_ctx *c, smm_csr *a, smm_csr *b, int flags
         PCHK(pool_get(c, (size_t)m, &p->d_tail));
         const int nd = p->n_bin[2];
         const int rgrid = (int)std::min<int64_t>((nd + 3) / 4, 65536);
+        const int tail_min = (flags & SMM_EXACT) ? TAIL_MIN_EXACT : TAIL_MIN_DEFAULT;
         if (p->list16)
             LAUNCH(c, "smm_runs", smm_runs<unsigned short>, rgrid, 256, 0, nd, p->g.nct, p->g.wc, (const int *)(p->d_lists + 2 * m), a->ptr,
-                   p->d_ub_off, p->d_rowcnt, p->d_P, (const unsigned short *)p->d_tmp, p->d_runs, p->d_tail, c->d_err);
+                   p->d_ub_off, p->d_rowcnt, p->d_P, (const unsigned short *)p->d_tmp, p->d_runs, p->d_tail, c->d_err, tail_min);
         else
             LAUNCH(c, "smm_runs", smm_runs<int>, rgrid, 256, 0, nd, p->g.nct, p->g.wc, (const int *)(p->d_lists + 2 * m), a->ptr,
-                   p->d_ub_off, p->d_rowcnt, p->d_P, (const int *)p->d_tmp, p->d_runs, p->d_tail, c->d_err);
+                   p->d_ub_off, p->d_rowcnt, p->d_P, (const int *)p->d_tmp, p->d_runs, p->d_tail, c->d_err, tail_min);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { smm_plan_destroy(p); return fail(SMM_ERR_HIP, "smm_runs: %s", hipGetErrorString(e)); }
     }

@@ -1161,10 +1161,10 @@ __global__ __launch_bounds__(256) void smm_symbolic_ccs(int m, int n_slabs, cons
 // load and two partial stores per sub-run.  Those steps get no sub-run table: the numeric epilogue walks the
 // list positions [P[e0], end) contiguously, 64 at a time, and every tile's unit keeps the columns that are
 // its own (positions in the list ARE positions in the result).  tail[row] = {e0, P[e0]}.
-#ifndef SMM_TAIL_MIN
-#define SMM_TAIL_MIN 64
-#endif
-constexpr int TAIL_MIN = SMM_TAIL_MIN;
+// tail_min is a kernel argument (round 4): 32 for the default walk (interleaved A/B in both orders at configs[1]: 8: 31.63,
+// 16: 31.38, 32: 31.13-31.22, 64: 31.26-31.47, 128: 31.37, 256: 31.92 ms per step), 64 for SMM_EXACT (8 waves share the
+// tail: 39.1 against 39.5 ms with 32).
+constexpr int TAIL_MIN_DEFAULT = 32, TAIL_MIN_EXACT = 64;
 constexpr int RUNS_WIN = 2048;
 template <typename LT>
 __global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc, const int *__restrict__ rowlist,
@@ -1173,7 +1173,8 @@ __global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc, const in
                                                 const int *__restrict__ rowcnt,
                                                 const unsigned *__restrict__ P,
                                                 const LT *__restrict__ tmp_idx,
-                                                unsigned *__restrict__ runs, int2 *__restrict__ tail, unsigned *__restrict__ err)
+                                                unsigned *__restrict__ runs, int2 *__restrict__ tail, unsigned *__restrict__ err,
+                                                int tail_min)
 {
     __shared__ int win_all[4][RUNS_WIN];
     constexpr int NV = RUNS_WIN / WAVE;            // window elements per lane
@@ -1191,7 +1192,7 @@ __global__ __launch_bounds__(256) void smm_runs(int m, int nct, int wc, const in
             const int e = eb + lane;
             if (e < a1) {
                 const unsigned q0 = P[e], q1 = e + 1 < a1 ? P[e + 1] : total;
-                if (q1 - q0 >= (unsigned)TAIL_MIN) e_last = e;
+                if (q1 - q0 >= (unsigned)tail_min) e_last = e;
             }
         }
         for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(e_last, o); e_last = y > e_last ? y : e_last; }
